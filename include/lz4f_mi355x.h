@@ -1,0 +1,257 @@
+/*
+ * lz4f_mi355x.h -- C ABI of liblz4f_mi355x.so: the MI355X-native LZ4 frame codec that drops in
+ * under Codec.Compression.LZ4.Conduit (nh2/lz4-frame-conduit).
+ *
+ * PART 1 is the drop-in boundary: exactly the twelve LZ4F_* entry points the reference's
+ * inline-c FFI binds (citations are /root/reference/src/Codec/Compression/LZ4/Conduit.hsc),
+ * with the struct layouts its Storable instances poke (CTypes.hsc:155-232).  The symbols are
+ * exported under BOTH the upstream names (LZ4F_compressUpdate ...) so that swapping the cabal
+ * `c-sources` for `extra-libraries: lz4f_mi355x` is the whole integration, and
+ * under an lz4f_mi355x_ prefix (same functions) for processes that also load liblz4.
+ * Every block is encoded / decoded / checksummed by HIP kernels on the GPU; there is no CPU
+ * fallback: with no usable device the calls return ERROR_GENERIC (and lz4f_mi355x_last_error()
+ * says why).
+ *
+ * PART 2 is the bulk extension the GPU needs (SURVEY.md section 8b "Bulk extension"): whole
+ * frames / many blocks per call, host-pointer and device-pointer variants.
+ */
+#ifndef LZ4F_MI355X_H
+#define LZ4F_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LZ4F_MI355X_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------------------------
+ * PART 1 -- the LZ4F-compatible streaming API (rows a1, a3, a6, a7 of SURVEY.md section 8a)
+ * ------------------------------------------------------------------------------------------ */
+
+#define LZ4F_VERSION          100   /* consumed at Conduit.hsc:199, :242, :568 */
+#define LZ4F_HEADER_SIZE_MIN  7
+#define LZ4F_HEADER_SIZE_MAX  19    /* consumed at Conduit.hsc:367, :466 */
+#define LZ4F_BLOCK_HEADER_SIZE 4
+#define LZ4F_BLOCK_CHECKSUM_SIZE 4
+#define LZ4F_CONTENT_CHECKSUM_SIZE 4
+
+typedef size_t LZ4F_errorCode_t;
+
+/* CTypes.hsc:48-66 (BlockSizeID) */
+typedef enum { LZ4F_default = 0, LZ4F_max64KB = 4, LZ4F_max256KB = 5, LZ4F_max1MB = 6, LZ4F_max4MB = 7 } LZ4F_blockSizeID_t;
+/* CTypes.hsc:77-91 (BlockMode) */
+typedef enum { LZ4F_blockLinked = 0, LZ4F_blockIndependent } LZ4F_blockMode_t;
+/* CTypes.hsc:98-112 (ContentChecksum) */
+typedef enum { LZ4F_noContentChecksum = 0, LZ4F_contentChecksumEnabled } LZ4F_contentChecksum_t;
+/* CTypes.hsc:117-131 (BlockChecksum) */
+typedef enum { LZ4F_noBlockChecksum = 0, LZ4F_blockChecksumEnabled } LZ4F_blockChecksum_t;
+/* CTypes.hsc:136-150 (FrameType) */
+typedef enum { LZ4F_frame = 0, LZ4F_skippableFrame } LZ4F_frameType_t;
+
+/* CTypes.hsc:155-199 (FrameInfo): 32 bytes; offsets 0,4,8,12,16,24,28 */
+typedef struct {
+    LZ4F_blockSizeID_t     blockSizeID;
+    LZ4F_blockMode_t       blockMode;
+    LZ4F_contentChecksum_t contentChecksumFlag;
+    LZ4F_frameType_t       frameType;
+    unsigned long long     contentSize;
+    unsigned               dictID;
+    LZ4F_blockChecksum_t   blockChecksumFlag;
+} LZ4F_frameInfo_t;
+
+/* CTypes.hsc:202-232 (Preferences): 56 bytes; offsets 0,32,36,40,44 */
+typedef struct {
+    LZ4F_frameInfo_t frameInfo;
+    int      compressionLevel;   /* only level <= 2 ("fast") exists here; the reference pins 0 (Conduit.hsc:260) */
+    unsigned autoFlush;
+    unsigned favorDecSpeed;
+    unsigned reserved[3];
+} LZ4F_preferences_t;
+
+typedef struct { unsigned stableSrc; unsigned reserved[3]; } LZ4F_compressOptions_t;
+typedef struct { unsigned stableDst; unsigned reserved[3]; } LZ4F_decompressOptions_t;
+
+typedef struct LZ4F_cctx_s LZ4F_cctx;   /* CTypes.hsc:235 */
+typedef struct LZ4F_dctx_s LZ4F_dctx;   /* CTypes.hsc:236 */
+
+/* Error enum order == upstream lz4frame.h (names surface verbatim as "lz4frame error: <name>",
+ * Conduit.hsc:160) */
+typedef enum {
+    LZ4F_OK_NoError = 0, LZ4F_ERROR_GENERIC, LZ4F_ERROR_maxBlockSize_invalid, LZ4F_ERROR_blockMode_invalid,
+    LZ4F_ERROR_contentChecksumFlag_invalid, LZ4F_ERROR_compressionLevel_invalid, LZ4F_ERROR_headerVersion_wrong,
+    LZ4F_ERROR_blockChecksum_invalid, LZ4F_ERROR_reservedFlag_set, LZ4F_ERROR_allocation_failed,
+    LZ4F_ERROR_srcSize_tooLarge, LZ4F_ERROR_dstMaxSize_tooSmall, LZ4F_ERROR_frameHeader_incomplete,
+    LZ4F_ERROR_frameType_unknown, LZ4F_ERROR_frameSize_wrong, LZ4F_ERROR_srcPtr_wrong,
+    LZ4F_ERROR_decompressionFailed, LZ4F_ERROR_headerChecksum_invalid, LZ4F_ERROR_contentChecksum_invalid,
+    LZ4F_ERROR_frameDecoding_alreadyStarted, LZ4F_ERROR_maxCode
+} LZ4F_errorCodes;
+
+/* replaces LZ4F_isError / LZ4F_getErrorName -- Conduit.hsc:149-153 (unsafe FFI call: never blocks) */
+LZ4F_MI355X_API unsigned    LZ4F_isError(LZ4F_errorCode_t code);
+LZ4F_MI355X_API const char* LZ4F_getErrorName(LZ4F_errorCode_t code);
+LZ4F_MI355X_API unsigned    LZ4F_getVersion(void);
+
+/* replaces LZ4F_createCompressionContext -- Conduit.hsc:199, :242 */
+LZ4F_MI355X_API LZ4F_errorCode_t LZ4F_createCompressionContext(LZ4F_cctx** cctxPtr, unsigned version);
+/* replaces LZ4F_freeCompressionContext -- Conduit.hsc:181, :210 (NULL is accepted) */
+LZ4F_MI355X_API LZ4F_errorCode_t LZ4F_freeCompressionContext(LZ4F_cctx* cctx);
+/* replaces LZ4F_compressBegin -- Conduit.hsc:292 */
+LZ4F_MI355X_API size_t LZ4F_compressBegin(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_preferences_t* prefsPtr);
+/* replaces LZ4F_compressBound -- Conduit.hsc:302 */
+LZ4F_MI355X_API size_t LZ4F_compressBound(size_t srcSize, const LZ4F_preferences_t* prefsPtr);
+/* replaces LZ4F_compressUpdate -- Conduit.hsc:311 (cOptPtr is always NULL there) */
+LZ4F_MI355X_API size_t LZ4F_compressUpdate(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity,
+                                           const void* srcBuffer, size_t srcSize, const LZ4F_compressOptions_t* cOptPtr);
+/* LZ4F_flush: not bound by the reference; LZ4F_compressEnd is defined in terms of it */
+LZ4F_MI355X_API size_t LZ4F_flush(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* cOptPtr);
+/* replaces LZ4F_compressEnd -- Conduit.hsc:321 */
+LZ4F_MI355X_API size_t LZ4F_compressEnd(LZ4F_cctx* cctx, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* cOptPtr);
+
+/* replaces LZ4F_createDecompressionContext -- Conduit.hsc:568 */
+LZ4F_MI355X_API LZ4F_errorCode_t LZ4F_createDecompressionContext(LZ4F_dctx** dctxPtr, unsigned version);
+/* replaces LZ4F_freeDecompressionContext -- Conduit.hsc:545 (NULL is accepted) */
+LZ4F_MI355X_API LZ4F_errorCode_t LZ4F_freeDecompressionContext(LZ4F_dctx* dctx);
+LZ4F_MI355X_API void   LZ4F_resetDecompressionContext(LZ4F_dctx* dctx);
+LZ4F_MI355X_API size_t LZ4F_headerSize(const void* src, size_t srcSize);
+/* replaces LZ4F_getFrameInfo -- Conduit.hsc:579 */
+LZ4F_MI355X_API size_t LZ4F_getFrameInfo(LZ4F_dctx* dctx, LZ4F_frameInfo_t* frameInfoPtr, const void* srcBuffer, size_t* srcSizePtr);
+/* replaces LZ4F_decompress -- Conduit.hsc:591 (dOptPtr is always NULL there) */
+LZ4F_MI355X_API size_t LZ4F_decompress(LZ4F_dctx* dctx, void* dstBuffer, size_t* dstSizePtr,
+                                       const void* srcBuffer, size_t* srcSizePtr, const LZ4F_decompressOptions_t* dOptPtr);
+
+/* the same twelve (+3) under a private prefix, for processes that also map liblz4 */
+LZ4F_MI355X_API unsigned    lz4f_mi355x_isError(size_t code);
+LZ4F_MI355X_API const char* lz4f_mi355x_getErrorName(size_t code);
+LZ4F_MI355X_API size_t lz4f_mi355x_createCompressionContext(LZ4F_cctx** cctxPtr, unsigned version);
+LZ4F_MI355X_API size_t lz4f_mi355x_freeCompressionContext(LZ4F_cctx* cctx);
+LZ4F_MI355X_API size_t lz4f_mi355x_compressBegin(LZ4F_cctx* cctx, void* dst, size_t cap, const LZ4F_preferences_t* prefs);
+LZ4F_MI355X_API size_t lz4f_mi355x_compressBound(size_t srcSize, const LZ4F_preferences_t* prefs);
+LZ4F_MI355X_API size_t lz4f_mi355x_compressUpdate(LZ4F_cctx* cctx, void* dst, size_t cap, const void* src, size_t n, const LZ4F_compressOptions_t* o);
+LZ4F_MI355X_API size_t lz4f_mi355x_flush(LZ4F_cctx* cctx, void* dst, size_t cap, const LZ4F_compressOptions_t* o);
+LZ4F_MI355X_API size_t lz4f_mi355x_compressEnd(LZ4F_cctx* cctx, void* dst, size_t cap, const LZ4F_compressOptions_t* o);
+LZ4F_MI355X_API size_t lz4f_mi355x_createDecompressionContext(LZ4F_dctx** dctxPtr, unsigned version);
+LZ4F_MI355X_API size_t lz4f_mi355x_freeDecompressionContext(LZ4F_dctx* dctx);
+LZ4F_MI355X_API size_t lz4f_mi355x_getFrameInfo(LZ4F_dctx* dctx, LZ4F_frameInfo_t* fi, const void* src, size_t* srcSize);
+LZ4F_MI355X_API size_t lz4f_mi355x_decompress(LZ4F_dctx* dctx, void* dst, size_t* dstSize, const void* src, size_t* srcSize, const LZ4F_decompressOptions_t* o);
+
+/* The two finalizers the reference defines verbatim in C (Conduit.hsc:163-189, :539-553) and
+ * takes the address of (Conduit.hsc:191, :555); shipped here so a binding that does not use
+ * inline-c still finds them. */
+LZ4F_MI355X_API void haskell_lz4_freeCompressionContext(LZ4F_cctx** ctxPtr);
+LZ4F_MI355X_API void haskell_lz4_freeDecompressionContext(LZ4F_dctx** ctxPtr);
+
+/* ------------------------------------------------------------------------------------------
+ * PART 2 -- bulk extension (new; what the batched conduits call).  All functions return an
+ * LZ4F-style size_t (test with LZ4F_isError).
+ * ------------------------------------------------------------------------------------------ */
+
+/* why the last failing call on this thread failed (HIP error text etc.); never NULL */
+LZ4F_MI355X_API const char* lz4f_mi355x_last_error(void);
+/* number of usable HIP devices (0 when there is none: every compute entry then fails loudly) */
+LZ4F_MI355X_API int lz4f_mi355x_device_count(void);
+/* which device the calling thread's contexts and engines are created on (default: 0, or the
+ * LZ4F_MI355X_DEVICE environment variable) */
+LZ4F_MI355X_API size_t lz4f_mi355x_set_device(int device);
+
+/* Worst-case size of a whole frame for srcSize bytes (header + blocks + EndMark + checksum). */
+LZ4F_MI355X_API size_t lz4f_mi355x_compressFrameBound(size_t srcSize, const LZ4F_preferences_t* prefs);
+
+/* Host-pointer bulk calls: one complete frame per call, blocks batched onto the GPU
+ * (pinned staging, H2D / kernels / D2H pipelined in slabs).  compressFrame == the bytes the
+ * streaming API would produce for the same input fed in < blockSize slices. */
+LZ4F_MI355X_API size_t lz4f_mi355x_compressFrame(void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                                                 const LZ4F_preferences_t* prefs);
+/* Decodes the first frame found in src. *srcConsumed (optional) = bytes of src used. */
+LZ4F_MI355X_API size_t lz4f_mi355x_decompressFrame(void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                                                   size_t* srcConsumed);
+
+/* ---- device-resident engine: everything stays in HBM, nothing synchronises with the host ---- */
+typedef struct lz4f_mi355x_engine lz4f_mi355x_engine;
+
+/* `hipStream` is a hipStream_t (NULL = the engine creates its own stream on `device`). */
+LZ4F_MI355X_API size_t lz4f_mi355x_engine_create(lz4f_mi355x_engine** out, int device, void* hipStream);
+LZ4F_MI355X_API size_t lz4f_mi355x_engine_free(lz4f_mi355x_engine* e);
+LZ4F_MI355X_API void*  lz4f_mi355x_engine_stream(lz4f_mi355x_engine* e);
+
+/* result record the device writes; read it back after synchronising the stream */
+typedef struct {
+    uint64_t size;        /* compress: frame bytes written; decompress: decoded bytes */
+    uint64_t consumed;    /* decompress: frame bytes consumed (incl. EndMark / checksum) */
+    uint32_t status;      /* LZ4F_errorCodes value, 0 = ok */
+    uint32_t n_blocks;
+    uint32_t first_bad_block;
+    uint32_t flags;       /* decoded FLG byte (decompress) */
+} lz4f_mi355x_result;
+
+/* Block table entry: where block i lives in the frame and in the output. */
+typedef struct {
+    uint64_t src_off;     /* offset of the payload (after the 4-byte size word) in the frame */
+    uint64_t dst_off;     /* offset of the decoded block in the output */
+    uint32_t word;        /* the size word as stored: bit31 = stored raw, bits 30..0 = payload bytes */
+    uint32_t dst_size;    /* decoded bytes (filled by decode; blockSize-capacity on input) */
+} lz4f_mi355x_block;
+
+/* Bytes of device workspace the engine will hold for inputs up to srcSize (informational). */
+LZ4F_MI355X_API size_t lz4f_mi355x_dev_workspace_size(size_t srcSize, const LZ4F_preferences_t* prefs);
+
+/* d_src[0..srcSize) -> one LZ4 frame at d_dst (device pointers).  Asynchronous on the engine's
+ * stream.  d_result (device, optional) receives size/status; d_table (device, optional,
+ * >= srcSize/blockSize+1 entries) receives the block table, which dev_decompressBlocks accepts
+ * back to skip the serial walk over the size words.
+ * Content checksum (serial over the whole stream by construction) is NOT computed on the device
+ * path: prefs with contentChecksumFlag set are rejected with ERROR_contentChecksumFlag_invalid;
+ * use the host-pointer calls for such frames.                                             */
+LZ4F_MI355X_API size_t lz4f_mi355x_dev_compressFrame(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity,
+                                                     const void* d_src, size_t srcSize, const LZ4F_preferences_t* prefs,
+                                                     lz4f_mi355x_result* d_result, lz4f_mi355x_block* d_table);
+
+/* First frame at d_frame[0..frameCapacity) -> d_dst.  Peeks the 7..19 header bytes (one small
+ * device->host copy), then everything is asynchronous: a walk kernel chases the size words, block
+ * checksums are verified on the GPU, blocks are decoded.  A content checksum present in the
+ * frame is skipped, not verified (see above).                                                 */
+LZ4F_MI355X_API size_t lz4f_mi355x_dev_decompressFrame(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity,
+                                                       const void* d_frame, size_t frameCapacity,
+                                                       lz4f_mi355x_result* d_result);
+
+/* Table-driven variant: the caller already has the block table (from dev_compressFrame, or from
+ * walking the size words on the host), so there is no walk and no host synchronisation at all.
+ * `info` carries blockSizeID / blockMode / blockChecksumFlag of the frame.                     */
+LZ4F_MI355X_API size_t lz4f_mi355x_dev_decompressBlocks(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity,
+                                                        const void* d_frame, size_t frameCapacity,
+                                                        const lz4f_mi355x_block* d_table, uint32_t n_blocks,
+                                                        const LZ4F_frameInfo_t* info, lz4f_mi355x_result* d_result);
+
+/* Per-block XXH32 of n_blocks byte ranges: d_out[i] = XXH32(d_base + off[i], len[i], 0) (row a5). */
+LZ4F_MI355X_API size_t lz4f_mi355x_dev_xxh32(lz4f_mi355x_engine* e, const void* d_base, const uint64_t* d_off,
+                                             const uint32_t* d_len, uint32_t n_blocks, uint32_t* d_out);
+
+/* ---- C++ mirror of the reference's conduits, driven through callbacks (host side above the
+ *      C ABI; see lz4_frame_conduit_amd/csrc/conduit.hpp).  `await` returns the next input chunk
+ *      (size 0 at end of stream: sets *data = NULL); `yield` receives each output ByteString. ---- */
+typedef size_t (*lz4f_mi355x_await_fn)(void* user, const void** data);
+typedef void   (*lz4f_mi355x_yield_fn)(void* user, const void* data, size_t size);
+/* compress = compressWithOutBufferSize 0 (Conduit.hsc:336-337, :457-533); prefs NULL = lz4DefaultPreferences */
+LZ4F_MI355X_API int lz4f_mi355x_conduit_compress(size_t outBufferSize, const LZ4F_preferences_t* prefs,
+                                                 lz4f_mi355x_await_fn await, lz4f_mi355x_yield_fn yield, void* user,
+                                                 char* errbuf, size_t errcap);
+/* compressYieldImmediately (Conduit.hsc:364-425) */
+LZ4F_MI355X_API int lz4f_mi355x_conduit_compress_yield_immediately(const LZ4F_preferences_t* prefs,
+                                                 lz4f_mi355x_await_fn await, lz4f_mi355x_yield_fn yield, void* user,
+                                                 char* errbuf, size_t errcap);
+/* decompress (Conduit.hsc:598-701) */
+LZ4F_MI355X_API int lz4f_mi355x_conduit_decompress(lz4f_mi355x_await_fn await, lz4f_mi355x_yield_fn yield, void* user,
+                                                 char* errbuf, size_t errcap);
+/* batched conduits (new): gather >= batchBytes of input per GPU call */
+LZ4F_MI355X_API int lz4f_mi355x_conduit_compress_batched(size_t batchBytes, const LZ4F_preferences_t* prefs,
+                                                 lz4f_mi355x_await_fn await, lz4f_mi355x_yield_fn yield, void* user,
+                                                 char* errbuf, size_t errcap);
+LZ4F_MI355X_API int lz4f_mi355x_conduit_decompress_batched(lz4f_mi355x_await_fn await, lz4f_mi355x_yield_fn yield, void* user,
+                                                 char* errbuf, size_t errcap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LZ4F_MI355X_H */

@@ -1,0 +1,99 @@
+// common.cuh -- shared device helpers for the gfx950 (CDNA4, wave64) LZ4 frame kernels.
+//
+// Everything here is byte/integer work bound by HBM and by dependent-load latency; there is no
+// matrix math anywhere on this path, so no MFMA.  Wave-uniform values are kept in SGPRs
+// (readfirstlane) so that the sequence parse runs on the scalar unit and the 64 lanes are spent on
+// the copies.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define WAVE 64
+
+namespace lz4f {
+
+typedef uint32_t u32_ua __attribute__((aligned(1)));
+struct __attribute__((packed, aligned(1))) b16_ua { uint32_t a, b, c, d; };   // 16 bytes, any alignment
+struct __attribute__((aligned(4))) w3_a4 { uint32_t a, b, c; };               // 3 dwords, dword aligned
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v)
+{
+    uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// status codes written by kernels (values of LZ4F_errorCodes that can arise on the device)
+enum : uint32_t { ST_OK = 0, ST_GENERIC = 1, ST_MAXBLOCK = 2, ST_BLOCKCK = 7, ST_DSTSMALL = 11, ST_DECOMP = 16 };
+
+// ---- XXH32 constants ----
+constexpr uint32_t XP1 = 2654435761u, XP2 = 2246822519u, XP3 = 3266489917u, XP4 = 668265263u, XP5 = 374761393u;
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+// ---- wave-cooperative copies (all arguments wave-uniform) --------------------------------------
+// Non-overlapping copy of len bytes, any alignment.  16 B per lane (1 KiB per wave instruction);
+// the ragged tail is one more 16-byte access ending exactly at len (rewrites identical bytes).
+__device__ __forceinline__ void wave_copy_disjoint(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src, uint32_t len)
+{
+    const uint32_t lane = lane_id();
+    if (len <= 16) {
+        if (lane < len) dst[lane] = src[lane];
+        return;
+    }
+    const uint32_t nfull = len >> 4, tail = len & 15;
+    for (uint32_t base = 0; base < nfull + (tail ? 1u : 0u); base += WAVE) {
+        const uint32_t c = base + lane;
+        if (c < nfull) {
+            *(b16_ua*)(dst + (size_t)c * 16) = *(const b16_ua*)(src + (size_t)c * 16);
+        } else if (c == nfull && tail) {
+            *(b16_ua*)(dst + len - 16) = *(const b16_ua*)(src + len - 16);
+        }
+    }
+}
+
+// LZ4 match copy: dst[i] = dst[i - offset] for i in [0,len), increasing i (forward overlap
+// semantics).  dst - offset .. dst is already written by THIS wave
+// (vector memory operations of one wave are performed in issue order), or by earlier kernels.
+__device__ __forceinline__ void wave_copy_match(uint8_t* dst, uint32_t offset, uint32_t len)
+{
+    const uint32_t lane = lane_id();
+    const uint8_t* src = dst - offset;
+    if (offset >= len) {                       // no self-overlap at all
+        wave_copy_disjoint(dst, src, len);
+        return;
+    }
+    uint32_t done = 0;
+    if (offset < 64) {
+        // short period: replicate the pattern bytewise until >= 1 KiB of it exists (or the match ends)
+        uint32_t idx = lane % offset;                 // (done + lane) % offset, kept incrementally
+        const uint32_t inc = WAVE % offset;
+        const uint32_t k = (1024 + offset - 1) / offset;          // widen to offset*k >= 1024 afterwards
+        const uint32_t need = (k - 1) * offset;
+        while (done < len && done < need) {
+            if (done + lane < len) dst[done + lane] = src[idx];
+            idx += inc; if (idx >= offset) idx -= offset;
+            done += WAVE;
+        }
+        if (done >= len) return;
+        offset *= k;                                  // dst[i] = dst[i - k*offset] holds once (k-1)*offset bytes exist
+        src = dst - offset;
+    }
+    // period >= 64: rounds of R = 16*floor(offset/16) <= 1024 bytes, 16 B per lane; a round never
+    // reads what it writes because R <= offset.
+    const uint32_t R = (offset >= 1024) ? 1024u : (offset & ~15u);
+    const uint32_t lanes_r = R >> 4;
+    while (done < len) {
+        const uint32_t left = len - done;
+        if (left >= R) {
+            if (lane < lanes_r) *(b16_ua*)(dst + done + lane * 16) = *(const b16_ua*)(src + done + lane * 16);
+            done += R;
+        } else {
+            // last partial round: left < R <= offset, so it is a disjoint copy
+            wave_copy_disjoint(dst + done, src + done, left);
+            done = len;
+        }
+    }
+}
+
+}  // namespace lz4f

@@ -1,0 +1,349 @@
+// encode.cuh -- LZ4 block encode on gfx950.
+//
+// Replaces the inner block loop of LZ4F_compressUpdate (called at
+// /root/reference/src/Codec/Compression/LZ4/Conduit.hsc:311): per frame block, greedy 4-byte
+// hash-table match finding and token / literal / offset / match-length emission.
+//
+// MI355X mapping (not a port of the CPU loop, which probes one position at a time):
+//   pass E1  find_matches  one wave per CHUNK of a frame block.  The 64 lanes probe 64 positions at
+//                          once against a private 4096 x u16 hash table in LDS (8 KiB per wave),
+//                          verify the candidates with a gather from the input, __ballot picks the
+//                          first hit, the wave extends it backwards/forwards 8 B per lane, and one
+//                          8-byte sequence record {literals, match length, offset} is appended.
+//                          Misses grow the probe stride like the CPU encoder's skip acceleration
+//                          (one stride step per 64 probes).  The table is pre-seeded from the
+//                          <= 64 KiB in front of the chunk, so chunking costs no matches.
+//   pass S   layout        sizes of all chunks/blocks (raw fallback when a block would not shrink),
+//                          exclusive scan -> final byte offset of every chunk in the frame; writes
+//                          size words, frame header, EndMark.
+//   pass E2  emit          one wave per chunk: tokens, length bytes, offsets and the literal copies
+//                          (16 B per lane) straight to their final position.
+// The output is a valid LZ4 block (end-of-block rules of Appendix A.2 are enforced); it is not
+// byte-identical to liblz4's -- parity is round-trip identity + ratio tolerance (tests/).
+#pragma once
+#include "common.cuh"
+
+namespace lz4f {
+
+constexpr uint32_t HASH_LOG = 12;
+constexpr uint32_t HASH_SIZE = 1u << HASH_LOG;          // entries (u16) per wave
+constexpr uint32_t MFLIMIT = 12, LASTLIT = 5, MINMATCH = 4;
+
+struct ChunkInfo {           // 32 bytes, one per chunk
+    uint32_t nrec;           // sequence records found
+    uint32_t first_lit;      // literal run of the first record (before carry-in)
+    uint32_t tail_lit;       // literals after the last match (whole chunk when nrec == 0)
+    uint32_t body_size;      // encoded bytes of all records as found (no carry-in, no final literals)
+    uint32_t carry_in;       // literals inherited from the preceding chunk(s)        [pass S]
+    uint32_t flags;          // bit0: block stored raw, bit1: last chunk of its block  [pass S]
+    uint64_t out_off;        // absolute offset in the frame of this chunk's first byte [pass S]
+};
+
+struct EncGeom {
+    uint64_t src_size;           // bytes readable at src (history + blocks)
+    uint64_t first_off;          // block 0 starts here; bytes in front of it are history (used when linked)
+    uint32_t write_endmark;      // 0: emit blocks only (streaming API), 1: header + blocks + EndMark
+    uint32_t block_size;
+    uint32_t chunk_size;         // divides block_size
+    uint32_t chunks_per_block;
+    uint32_t n_blocks;
+    uint32_t n_chunks;
+    uint32_t linked;             // matches may reach 64 KiB back across block starts
+    uint32_t block_checksum;
+    uint32_t header_size;
+    uint8_t  header[20];
+    uint32_t max_rec_per_chunk;  // record slots per chunk
+};
+
+__device__ __forceinline__ uint32_t len_ext_bytes(uint32_t v) { return v >= 15 ? (v - 15) / 255 + 1 : 0; }
+__device__ __forceinline__ uint32_t seq_size(uint32_t lit, uint32_t mlen)
+{
+    return 1 + len_ext_bytes(lit) + lit + 2 + len_ext_bytes(mlen - MINMATCH);
+}
+__device__ __forceinline__ uint64_t pack_rec(uint32_t lit, uint32_t mlen, uint32_t off)
+{
+    return (uint64_t)lit | ((uint64_t)mlen << 24) | ((uint64_t)off << 48);
+}
+
+__device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return *(const u32_ua*)p; }
+typedef uint64_t u64_ua __attribute__((aligned(1)));
+// 8 bytes at p, never reading at or beyond `end`
+__device__ __forceinline__ uint64_t ld64_guard(const uint8_t* p, const uint8_t* end)
+{
+    if (p + 8 <= end) return *(const u64_ua*)p;
+    uint64_t v = 0;
+    for (int i = 0; i < 8; i++) if (p + i < end) v |= (uint64_t)p[i] << (8 * i);
+    return v;
+}
+
+// ------------------------------- pass E1 -------------------------------------------------------
+// grid: one wave per chunk (blockDim = 64 * WAVES_PER_WG)
+template <int WAVES_PER_WG>
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_t* __restrict__ src, EncGeom g,
+                                                                    ChunkInfo* __restrict__ info, uint64_t* __restrict__ recs)
+{
+    __shared__ uint16_t s_table[WAVES_PER_WG][HASH_SIZE];
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t chunk = uni(blockIdx.x * WAVES_PER_WG + wave);
+    if (chunk >= g.n_chunks) return;
+    uint16_t* table = s_table[wave];
+
+    const uint32_t blk = chunk / g.chunks_per_block, cib = chunk % g.chunks_per_block;
+    const uint64_t bstart = g.first_off + (uint64_t)blk * g.block_size;
+    const uint64_t bend_abs = (bstart + g.block_size < g.src_size) ? bstart + g.block_size : g.src_size;
+    const uint64_t cs_abs = bstart + (uint64_t)cib * g.chunk_size;
+    ChunkInfo* ci = info + chunk;
+    if (cs_abs >= bend_abs) {               // chunk beyond a short last block
+        if (lane == 0) { ci->nrec = 0; ci->first_lit = 0; ci->tail_lit = 0; ci->body_size = 0; }
+        return;
+    }
+    const uint64_t ce_abs = (cs_abs + g.chunk_size < bend_abs) ? cs_abs + g.chunk_size : bend_abs;
+    const uint64_t low_abs = g.linked ? 0 : bstart;                  // matches may not start before this
+    const uint32_t back = (uint32_t)((cs_abs - low_abs < 65536u) ? (cs_abs - low_abs) : 65536u);
+    const uint8_t* base = src + (cs_abs - back);                     // position 0
+    const uint8_t* rd_end = src + g.src_size;                        // nothing is read at or beyond this
+    const uint32_t cs = back, ce = back + (uint32_t)(ce_abs - cs_abs);
+    const uint32_t bend = back + (uint32_t)(bend_abs - cs_abs);
+    uint64_t* rec = recs + (uint64_t)chunk * g.max_rec_per_chunk;
+
+    // clear + pre-seed the table with the history in front of the chunk
+    for (uint32_t i = lane; i < HASH_SIZE / 2; i += WAVE) ((uint32_t*)table)[i] = 0;
+    for (uint32_t q = 0; q + 4 <= back; q += WAVE) {
+        const uint32_t p = q + lane;
+        if (p + 4 <= back) table[(ld32(base + p) * 2654435761u) >> (32 - HASH_LOG)] = (uint16_t)p;
+    }
+
+    uint32_t nrec = 0, first_lit = 0, body = 0;
+    uint32_t anchor = cs;
+    // a match may start at p iff p + 4 <= ce and p + MFLIMIT <= bend; it may end at min(ce, bend - LASTLIT).
+    // Blocks shorter than MFLIMIT+1 bytes are literals only (Appendix A.2).
+    const uint32_t blen = (uint32_t)(bend_abs - bstart), clen = ce - cs;
+    bool searchable = blen >= MFLIMIT + 1 && clen >= MINMATCH;
+    uint32_t last_start = 0, end_lim = 0;
+    if (searchable) {
+        last_start = (ce - MINMATCH < bend - MFLIMIT) ? ce - MINMATCH : bend - MFLIMIT;
+        end_lim = (ce < bend - LASTLIT) ? ce : bend - LASTLIT;
+        searchable = last_start >= cs;
+    }
+    if (searchable) {
+        uint32_t ip = cs, step = 1;
+        while (ip <= last_start) {
+            const uint32_t p = ip + lane * step;
+            const bool act = p <= last_start;
+            uint32_t seq = 0, e = 0, h = 0;
+            if (act) {
+                seq = ld32(base + p);
+                h = (seq * 2654435761u) >> (32 - HASH_LOG);
+                e = table[h];
+            }
+            // all probes of this step read the table before any of them writes it
+            __builtin_amdgcn_wave_barrier();
+            if (act) table[h] = (uint16_t)p;
+            const uint32_t d = (p - e) & 0xFFFFu;
+            const bool ok = act && d != 0 && d <= p;
+            const uint32_t cand = p - d;
+            uint32_t cseq = ~seq;
+            if (ok) cseq = ld32(base + cand);
+            const uint64_t hits = __ballot(ok && cseq == seq);
+            if (hits == 0) {
+                ip += WAVE * step;
+                step += 1;
+                continue;
+            }
+            const uint32_t L = (uint32_t)__builtin_ctzll(hits);
+            uint32_t mp = __builtin_amdgcn_readlane(p, L);
+            uint32_t mc = __builtin_amdgcn_readlane(cand, L);
+            // backward extension over pending literals
+            {
+                uint32_t room = mp - anchor; if (mc < room) room = mc;
+                while (room) {
+                    const uint32_t k = lane + 1;
+                    const bool in = k <= room;
+                    const bool eq = in && base[mp - k] == base[mc - k];
+                    const uint64_t ne = __ballot(!eq);
+                    const uint32_t nb = ne ? (uint32_t)__builtin_ctzll(ne) : WAVE;
+                    mp -= nb; mc -= nb; room -= nb;
+                    if (nb < WAVE) break;
+                }
+            }
+            // forward extension, 8 B per lane, stopping at end_lim
+            uint32_t mlen = MINMATCH;
+            for (;;) {
+                const uint32_t a = mp + mlen + lane * 8;
+                uint32_t good = 0;                 // equal bytes in my 8-byte window (clipped at end_lim)
+                if (a < end_lim) {
+                    const uint64_t x = ld64_guard(base + a, rd_end) ^ ld64_guard(base + (a - (mp - mc)), rd_end);
+                    good = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8;
+                    const uint32_t room = end_lim - a;
+                    if (good > room) good = room;
+                }
+                const uint64_t stop = __ballot(good < 8);
+                if (stop == 0) { mlen += WAVE * 8; continue; }
+                const uint32_t f = (uint32_t)__builtin_ctzll(stop);
+                mlen += f * 8 + __builtin_amdgcn_readlane(good, f);
+                break;
+            }
+            // append the sequence record
+            const uint32_t lit = mp - anchor;
+            if (lane == 0) rec[nrec] = pack_rec(lit, mlen, mp - mc);
+            if (nrec == 0) first_lit = lit;
+            body += seq_size(lit, mlen);
+            nrec++;
+            anchor = ip = mp + mlen;
+            step = 1;
+            if (nrec >= g.max_rec_per_chunk) break;          // cannot happen with ceil(chunk/4) slots; belt and braces
+        }
+    }
+    if (lane == 0) { ci->nrec = nrec; ci->first_lit = first_lit; ci->tail_lit = ce - anchor; ci->body_size = body; }
+}
+
+// ------------------------------- pass S --------------------------------------------------------
+struct BlockOut {            // mirrors lz4f_mi355x_block
+    uint64_t src_off, dst_off;
+    uint32_t word, dst_size;
+};
+struct ResultRec {           // mirrors lz4f_mi355x_result
+    uint64_t size, consumed;
+    uint32_t status, n_blocks, first_bad_block, flags;
+};
+
+// one workgroup of 1024 threads: per-block sizes, then a chunked exclusive scan over the blocks
+__global__ __launch_bounds__(1024) void k_layout(EncGeom g, ChunkInfo* __restrict__ info, BlockOut* __restrict__ table,
+                                                 uint32_t* __restrict__ blk_bytes /* n_blocks scratch */,
+                                                 uint8_t* __restrict__ dst, uint64_t dst_cap, ResultRec* __restrict__ res)
+{
+    __shared__ uint64_t s_part[1024];
+    __shared__ uint64_t s_carry;
+    const uint32_t t = threadIdx.x;
+    // 1) per block: walk its chunks, fix carries, decide raw
+    for (uint32_t b = t; b < g.n_blocks; b += 1024) {
+        const uint64_t bstart = g.first_off + (uint64_t)b * g.block_size;
+        const uint32_t blen = (uint32_t)((bstart + g.block_size < g.src_size) ? g.block_size : g.src_size - bstart);
+        ChunkInfo* ci = info + (uint64_t)b * g.chunks_per_block;
+        const uint32_t nch = (blen + g.chunk_size - 1) / g.chunk_size;
+        uint32_t carry = 0, total = 0;
+        for (uint32_t c = 0; c < nch; c++) {
+            ChunkInfo x = ci[c];
+            ci[c].carry_in = carry;
+            ci[c].out_off = total;                 // relative for now
+            ci[c].flags = (c + 1 == nch) ? 2u : 0u;
+            if (x.nrec) {
+                total += x.body_size + carry + len_ext_bytes(x.first_lit + carry) - len_ext_bytes(x.first_lit);
+                carry = x.tail_lit;
+            } else carry += x.tail_lit;
+        }
+        total += 1 + len_ext_bytes(carry) + carry;  // final literal-only sequence
+        const bool raw = total >= blen;             // LZ4F stores raw when it does not fit blockSize-1
+        const uint32_t payload = raw ? blen : total;
+        if (raw) for (uint32_t c = 0; c < nch; c++) ci[c].flags |= 1u;
+        table[b].word = raw ? (blen | 0x80000000u) : total;
+        table[b].dst_off = bstart - g.first_off;
+        table[b].dst_size = blen;
+        blk_bytes[b] = 4 + payload + 4 * g.block_checksum;
+    }
+    __syncthreads();
+    // 2) exclusive scan of blk_bytes in tiles of 1024
+    if (t == 0) s_carry = g.header_size;
+    __syncthreads();
+    for (uint32_t base = 0; base < g.n_blocks; base += 1024) {
+        const uint32_t b = base + t;
+        const uint64_t v = (b < g.n_blocks) ? blk_bytes[b] : 0;
+        s_part[t] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan
+            uint64_t add = (t >= off) ? s_part[t - off] : 0;
+            __syncthreads();
+            s_part[t] += add;
+            __syncthreads();
+        }
+        const uint64_t excl = s_carry + s_part[t] - v;
+        if (b < g.n_blocks) table[b].src_off = excl + 4;          // payload follows the size word
+        __syncthreads();
+        if (t == 1023) s_carry += s_part[1023];
+        __syncthreads();
+    }
+    const uint64_t frame_size = s_carry + (g.write_endmark ? 4 : 0);
+    const bool fits = frame_size <= dst_cap;
+    // 3) absolute chunk offsets, size words, header, EndMark
+    if (fits) {
+        for (uint32_t b = t; b < g.n_blocks; b += 1024) {
+            const uint64_t pay = table[b].src_off;
+            const uint32_t w = table[b].word;
+            dst[pay - 4] = (uint8_t)w; dst[pay - 3] = (uint8_t)(w >> 8); dst[pay - 2] = (uint8_t)(w >> 16); dst[pay - 1] = (uint8_t)(w >> 24);
+            ChunkInfo* ci = info + (uint64_t)b * g.chunks_per_block;
+            const uint32_t blen = table[b].dst_size;
+            const uint32_t nch = (blen + g.chunk_size - 1) / g.chunk_size;
+            for (uint32_t c = 0; c < nch; c++)
+                ci[c].out_off = (w >> 31) ? pay + (uint64_t)c * g.chunk_size : pay + ci[c].out_off;
+        }
+        if (t < g.header_size) dst[t] = g.header[t];
+        if (t < 4 && g.write_endmark) dst[s_carry + t] = 0;
+    }
+    if (t == 0 && res) {
+        res->size = fits ? frame_size : 0; res->consumed = g.src_size - g.first_off;
+        res->status = fits ? ST_OK : ST_DSTSMALL; res->n_blocks = g.n_blocks; res->first_bad_block = 0xFFFFFFFFu; res->flags = g.header[4];
+    }
+    if (!fits) for (uint32_t c = t; c < g.n_chunks; c += 1024) info[c].flags |= 4u;   // tell pass E2 to do nothing
+}
+
+// ------------------------------- pass E2 -------------------------------------------------------
+__device__ __forceinline__ void emit_len_ext(uint8_t* p, uint32_t v /* value minus 15 */)
+{
+    const uint32_t n255 = v / 255, lane = lane_id();
+    for (uint32_t i = lane; i < n255; i += WAVE) p[i] = 255;
+    if (lane == 0) p[n255] = (uint8_t)(v - n255 * 255);
+}
+
+template <int WAVES_PER_WG>
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void k_emit(const uint8_t* __restrict__ src, EncGeom g,
+                                                            const ChunkInfo* __restrict__ info, const uint64_t* __restrict__ recs,
+                                                            uint8_t* __restrict__ dst)
+{
+    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t chunk = uni(blockIdx.x * WAVES_PER_WG + wave);
+    if (chunk >= g.n_chunks) return;
+    const uint32_t blk = chunk / g.chunks_per_block, cib = chunk % g.chunks_per_block;
+    const uint64_t bstart = g.first_off + (uint64_t)blk * g.block_size;
+    const uint64_t bend_abs = (bstart + g.block_size < g.src_size) ? bstart + g.block_size : g.src_size;
+    const uint64_t cs_abs = bstart + (uint64_t)cib * g.chunk_size;
+    if (cs_abs >= bend_abs) return;
+    const uint64_t ce_abs = (cs_abs + g.chunk_size < bend_abs) ? cs_abs + g.chunk_size : bend_abs;
+    const ChunkInfo ci = info[chunk];
+    if (ci.flags & 4u) return;
+    uint8_t* o = dst + ci.out_off;
+    if (ci.flags & 1u) {                                   // stored block: this chunk's slice of it
+        const uint64_t n = ce_abs - cs_abs;
+        for (uint64_t off = 0; off < n; off += 1u << 20) {
+            const uint32_t m = (uint32_t)((n - off < (1u << 20)) ? n - off : (1u << 20));
+            wave_copy_disjoint(o + off, src + cs_abs + off, m);
+        }
+        return;
+    }
+    const uint64_t* rec = recs + (uint64_t)chunk * g.max_rec_per_chunk;
+    const uint8_t* lp = src + (cs_abs - ci.carry_in);       // start of the pending literal run
+    for (uint32_t r = 0; r < ci.nrec; r++) {
+        const uint64_t x = rec[r];
+        uint32_t lit = (uint32_t)(x & 0xFFFFFFu);
+        const uint32_t mlen = (uint32_t)((x >> 24) & 0xFFFFFFu), off = (uint32_t)(x >> 48);
+        if (r == 0) lit += ci.carry_in;
+        const uint32_t mcode = mlen - MINMATCH;
+        if (lane == 0) *o = (uint8_t)(((lit < 15 ? lit : 15) << 4) | (mcode < 15 ? mcode : 15));
+        o += 1;
+        if (lit >= 15) { emit_len_ext(o, lit - 15); o += len_ext_bytes(lit); }
+        wave_copy_disjoint(o, lp, lit);
+        o += lit;
+        if (lane == 0) { o[0] = (uint8_t)off; o[1] = (uint8_t)(off >> 8); }
+        o += 2;
+        if (mcode >= 15) { emit_len_ext(o, mcode - 15); o += len_ext_bytes(mcode); }
+        lp += lit + mlen;
+    }
+    if (ci.flags & 2u) {                                   // last chunk: final literal-only sequence
+        const uint32_t lit = ci.nrec ? ci.tail_lit : ci.tail_lit + ci.carry_in;
+        if (lane == 0) *o = (uint8_t)((lit < 15 ? lit : 15) << 4);
+        o += 1;
+        if (lit >= 15) { emit_len_ext(o, lit - 15); o += len_ext_bytes(lit); }
+        wave_copy_disjoint(o, lp, lit);
+    }
+}
+
+}  // namespace lz4f

@@ -1,0 +1,466 @@
+// engine.hip -- kernels (via the .cuh headers) + their launch plumbing + the device-pointer C ABI.
+// Target: gfx950 only (MI355X).  No CPU fallback: without a usable device every entry fails loudly.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "engine.hpp"
+#include "frame_dev.cuh"
+
+using namespace lz4f;
+
+static_assert(sizeof(BlockOut) == sizeof(lz4f_mi355x_block), "block table layout");
+static_assert(sizeof(ResultRec) == sizeof(lz4f_mi355x_result), "result layout");
+static_assert(sizeof(ChunkInfo) == 32, "chunk info layout");
+
+namespace lz4f {
+
+static thread_local char t_err[512] = "";
+static thread_local int t_device = -1;
+static thread_local lz4f_mi355x_engine* t_engine = nullptr;
+
+void set_last_error(const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt); vsnprintf(t_err, sizeof(t_err), fmt, ap); va_end(ap);
+}
+const char* last_error() { return t_err; }
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            set_last_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__);  \
+            return make_err(LZ4F_ERROR_GENERIC);                                                        \
+        }                                                                                               \
+    } while (0)
+
+int DevBuf::ensure(size_t n)
+{
+    if (n <= cap) return 0;
+    size_t want = n + n / 8 + 4096;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) { set_last_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e)); p = nullptr; return 1; }
+    cap = want;
+    return 0;
+}
+void DevBuf::release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+int PinBuf::ensure(size_t n)
+{
+    if (n <= cap) return 0;
+    size_t want = n + n / 8 + 4096;
+    if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) { set_last_error("hipHostMalloc(%zu) failed: %s", want, hipGetErrorString(e)); p = nullptr; return 1; }
+    cap = want;
+    return 0;
+}
+void PinBuf::release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+
+int selected_device()
+{
+    if (t_device < 0) {
+        const char* s = getenv("LZ4F_MI355X_DEVICE");
+        t_device = s ? atoi(s) : 0;
+    }
+    return t_device;
+}
+
+uint32_t pick_chunk_size(uint32_t block_size)
+{
+    uint32_t c = 128u << 10;
+    if (const char* s = getenv("LZ4F_MI355X_CHUNK")) { uint32_t v = (uint32_t)atoi(s); if (v >= 4096 && (v & (v - 1)) == 0) c = v; }
+    return block_size < c ? block_size : c;
+}
+
+size_t new_engine(lz4f_mi355x_engine** out, int device, void* stream)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_last_error("no usable HIP device (hipGetDeviceCount: %s, count %d): liblz4f_mi355x has no CPU fallback", hipGetErrorString(e), n);
+        return make_err(LZ4F_ERROR_GENERIC);
+    }
+    if (device < 0 || device >= n) { set_last_error("device %d out of range (%d devices)", device, n); return make_err(LZ4F_ERROR_GENERIC); }
+    HIP_TRY(hipSetDevice(device));
+    lz4f_mi355x_engine* en = new lz4f_mi355x_engine();
+    en->device = device;
+    if (stream) { en->stream = stream; en->own_stream = false; }
+    else {
+        hipStream_t s;
+        hipError_t e2 = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+        if (e2 != hipSuccess) { delete en; set_last_error("hipStreamCreate failed: %s", hipGetErrorString(e2)); return make_err(LZ4F_ERROR_GENERIC); }
+        en->stream = s; en->own_stream = true;
+    }
+    *out = en;
+    return 0;
+}
+
+size_t thread_engine(lz4f_mi355x_engine** out)
+{
+    if (!t_engine) {
+        size_t r = new_engine(&t_engine, selected_device(), nullptr);
+        if (is_err(r)) { t_engine = nullptr; return r; }
+    }
+    *out = t_engine;
+    return 0;
+}
+
+}  // namespace lz4f
+
+lz4f_mi355x_engine::~lz4f_mi355x_engine()
+{
+    (void)hipSetDevice(device);
+    if (stream) (void)hipStreamSynchronize((hipStream_t)stream);
+    info.release(); recs.release(); table.release(); blk_bytes.release(); res.release(); bad.release();
+    d_in.release(); d_out.release();
+    h_in.release(); h_out.release(); h_small.release();
+    if (own_stream && stream) (void)hipStreamDestroy((hipStream_t)stream);
+}
+
+size_t lz4f_mi355x_engine::sync()
+{
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst, uint64_t dst_cap,
+                                           lz4f_mi355x_result* d_res, lz4f_mi355x_block* d_table)
+{
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    EncGeom g;
+    memset(&g, 0, sizeof(g));
+    g.src_size = j.src_size; g.first_off = j.first_off; g.write_endmark = j.endmark ? 1 : 0;
+    g.block_size = j.block_size;
+    g.chunk_size = pick_chunk_size(j.block_size);
+    g.chunks_per_block = j.block_size / g.chunk_size;
+    const uint64_t payload = j.src_size - j.first_off;
+    const uint64_t nb = (payload + j.block_size - 1) / j.block_size;
+    if (nb > 0x7FFFFFFFull / g.chunks_per_block) { set_last_error("input too large for one call"); return make_err(LZ4F_ERROR_srcSize_tooLarge); }
+    g.n_blocks = (uint32_t)nb; g.n_chunks = g.n_blocks * g.chunks_per_block;
+    g.linked = j.linked; g.block_checksum = j.block_checksum;
+    g.header_size = j.header_size; memcpy(g.header, j.header, j.header_size);
+    g.max_rec_per_chunk = g.chunk_size / 4 + 1;
+
+    if (info.ensure((size_t)(g.n_chunks + 1) * sizeof(ChunkInfo))) return make_err(LZ4F_ERROR_allocation_failed);
+    if (recs.ensure((size_t)(g.n_chunks + 1) * g.max_rec_per_chunk * 8)) return make_err(LZ4F_ERROR_allocation_failed);
+    if (blk_bytes.ensure((size_t)(g.n_blocks + 1) * 4)) return make_err(LZ4F_ERROR_allocation_failed);
+    if (!d_table) { if (table.ensure((size_t)(g.n_blocks + 1) * sizeof(BlockOut))) return make_err(LZ4F_ERROR_allocation_failed); d_table = (lz4f_mi355x_block*)table.p; }
+    if (!d_res) { if (res.ensure(sizeof(ResultRec))) return make_err(LZ4F_ERROR_allocation_failed); d_res = (lz4f_mi355x_result*)res.p; }
+
+    constexpr int W = 4;
+    if (g.n_chunks) {
+        hipLaunchKernelGGL((k_find_matches<W>), dim3((g.n_chunks + W - 1) / W), dim3(64 * W), 0, st, j.d_src, g,
+                           (ChunkInfo*)info.p, (uint64_t*)recs.p);
+    }
+    hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, g, (ChunkInfo*)info.p, (BlockOut*)d_table, (uint32_t*)blk_bytes.p,
+                       d_dst, dst_cap, (ResultRec*)d_res);
+    if (g.n_chunks) {
+        hipLaunchKernelGGL((k_emit<W>), dim3((g.n_chunks + W - 1) / W), dim3(64 * W), 0, st, j.d_src, g, (const ChunkInfo*)info.p,
+                           (const uint64_t*)recs.p, d_dst);
+        if (j.block_checksum)
+            hipLaunchKernelGGL((k_xxh32_blocks<W>), dim3((g.n_blocks + W - 1) / W), dim3(64 * W), 0, st, d_dst, (BlockOut*)d_table,
+                               (const ResultRec*)d_res, g.n_blocks, 0u, (uint32_t*)nullptr);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x_result* d_res)
+{
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    if (!d_res) { if (res.ensure(sizeof(ResultRec))) return make_err(LZ4F_ERROR_allocation_failed); d_res = (lz4f_mi355x_result*)res.p; }
+    if (bad.ensure(64)) return make_err(LZ4F_ERROR_allocation_failed);
+    BlockOut* tbl;
+    uint32_t n_max;
+    if (j.d_table || j.table_in_place) {
+        // caller-supplied table: work on a copy (decode overwrites dst_size)
+        n_max = j.n_blocks;
+        if (table.ensure((size_t)(n_max + 1) * sizeof(BlockOut))) return make_err(LZ4F_ERROR_allocation_failed);
+        tbl = (BlockOut*)table.p;
+        if (!j.table_in_place)
+            HIP_TRY(hipMemcpyAsync(tbl, j.d_table, (size_t)n_max * sizeof(BlockOut), hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_init_result, dim3(1), dim3(64), 0, st, (ResultRec*)d_res, n_max, 0u);
+    } else {
+        n_max = j.max_blocks;
+        if (table.ensure((size_t)(n_max + 1) * sizeof(BlockOut))) return make_err(LZ4F_ERROR_allocation_failed);
+        tbl = (BlockOut*)table.p;
+        hipLaunchKernelGGL(k_walk_frame, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, j.dst_cap, tbl, n_max, (ResultRec*)d_res);
+    }
+    HIP_TRY(hipMemsetAsync(bad.p, 0xFF, 4, st));
+    constexpr int W = 4;
+    const uint32_t grid = j.linked ? 1u : (n_max + W - 1) / W;
+    if (n_max) {
+        if (j.block_checksum)
+            hipLaunchKernelGGL((k_xxh32_blocks<W>), dim3((n_max + W - 1) / W), dim3(64 * W), 0, st, (uint8_t*)j.d_frame, tbl,
+                               (const ResultRec*)d_res, n_max, 1u, (uint32_t*)bad.p);
+        hipLaunchKernelGGL((k_decode_blocks<W>), dim3(grid), dim3(64 * W), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl, (const ResultRec*)d_res,
+                           n_max, j.linked ? 1u : 0u, j.block_size, j.hist0);
+    }
+    hipLaunchKernelGGL(k_finish_decode, dim3(1), dim3(64), 0, st, j.d_dst, tbl, (ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size,
+                       j.block_checksum ? (const uint32_t*)bad.p : (const uint32_t*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-pointer helpers
+size_t lz4f_mi355x_engine::compress_blocks_host(const uint8_t* src, size_t n, const uint8_t* hist, size_t hist_len,
+                                                uint32_t block_size, bool linked, bool block_checksum, std::vector<uint8_t>& out)
+{
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    if (!linked) hist_len = 0;
+    if (hist_len > 65536) { hist += hist_len - 65536; hist_len = 65536; }
+    const size_t total = hist_len + n;
+    const size_t nblocks = (n + block_size - 1) / block_size;
+    const size_t out_cap = n + nblocks * 8 + 64;
+    if (h_in.ensure(total) || d_in.ensure(total + 64) || d_out.ensure(out_cap) || h_out.ensure(out_cap + sizeof(ResultRec)) || res.ensure(sizeof(ResultRec)))
+        return make_err(LZ4F_ERROR_allocation_failed);
+    if (hist_len) memcpy(h_in.p, hist, hist_len);
+    memcpy((uint8_t*)h_in.p + hist_len, src, n);
+    HIP_TRY(hipMemcpyAsync(d_in.p, h_in.p, total, hipMemcpyHostToDevice, st));
+    CompressJob j; memset(&j, 0, sizeof(j));
+    j.d_src = (const uint8_t*)d_in.p; j.src_size = total; j.first_off = hist_len; j.block_size = block_size;
+    j.linked = linked; j.block_checksum = block_checksum; j.endmark = false; j.header_size = 0;
+    size_t r = launch_compress(j, (uint8_t*)d_out.p, out_cap, (lz4f_mi355x_result*)res.p, nullptr);
+    if (is_err(r)) return r;
+    ResultRec* hr = (ResultRec*)((uint8_t*)h_out.p + out_cap);
+    HIP_TRY(hipMemcpyAsync(hr, res.p, sizeof(ResultRec), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (hr->status != ST_OK) { set_last_error("device compress status %u", hr->status); return make_err((int)hr->status); }
+    HIP_TRY(hipMemcpyAsync(h_out.p, d_out.p, hr->size, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    out.insert(out.end(), (uint8_t*)h_out.p, (uint8_t*)h_out.p + hr->size);
+    return 0;
+}
+
+static size_t status_to_err(uint32_t st)
+{
+    return st == ST_OK ? 0 : make_err((int)st);
+}
+
+size_t lz4f_mi355x_engine::run_decode_slab(const uint8_t* frame_part, size_t part_len, const std::vector<lz4f_mi355x_block>& entries,
+                                           const ParsedHeader& ph, const uint8_t* hist, size_t hist_len, uint8_t* dst, size_t dst_room, size_t* got)
+{
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    const bool linked = ph.info.blockMode == LZ4F_blockLinked;
+    if (!linked) hist_len = 0;
+    const size_t nb = entries.size();
+    const size_t out_room = std::min(dst_room, nb * ph.max_block);
+    const size_t tbytes = nb * sizeof(BlockOut);
+    if (h_in.ensure(part_len + tbytes + hist_len + 64) || d_in.ensure(part_len + 64) || d_out.ensure(hist_len + out_room + 64) ||
+        h_out.ensure(out_room + sizeof(ResultRec) + 64) || res.ensure(sizeof(ResultRec)) || table.ensure((nb + 1) * sizeof(BlockOut)))
+        return make_err(LZ4F_ERROR_allocation_failed);
+    uint8_t* hp = (uint8_t*)h_in.p;
+    memcpy(hp, frame_part, part_len);
+    memcpy(hp + part_len, entries.data(), tbytes);
+    if (hist_len) memcpy(hp + part_len + tbytes, hist, hist_len);
+    HIP_TRY(hipMemcpyAsync(d_in.p, hp, part_len, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(table.p, hp + part_len, tbytes, hipMemcpyHostToDevice, st));
+    if (hist_len) HIP_TRY(hipMemcpyAsync(d_out.p, hp + part_len + tbytes, hist_len, hipMemcpyHostToDevice, st));
+    DecompressJob j; memset(&j, 0, sizeof(j));
+    j.d_frame = (const uint8_t*)d_in.p; j.frame_cap = part_len; j.d_dst = (uint8_t*)d_out.p + hist_len; j.dst_cap = out_room; j.hist0 = hist_len;
+    j.block_size = (uint32_t)ph.max_block; j.linked = linked; j.block_checksum = ph.info.blockChecksumFlag != 0;
+    j.table_in_place = true; j.n_blocks = (uint32_t)nb; j.max_blocks = (uint32_t)nb;
+    size_t r = launch_decompress(j, (lz4f_mi355x_result*)res.p);
+    if (is_err(r)) return r;
+    ResultRec* hr = (ResultRec*)((uint8_t*)h_out.p + out_room + 32 - ((out_room + 32) & 7) + 8);
+    HIP_TRY(hipMemcpyAsync(hr, res.p, sizeof(ResultRec), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (hr->status != ST_OK) { set_last_error("device decode status %u at block %u", hr->status, hr->first_bad_block); return status_to_err(hr->status); }
+    if (hr->size > dst_room) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
+    HIP_TRY(hipMemcpyAsync(h_out.p, (uint8_t*)d_out.p + hist_len, hr->size, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(dst, h_out.p, hr->size);
+    *got = hr->size;
+    return 0;
+}
+
+size_t lz4f_mi355x_engine::decompress_block_host(const uint8_t* payload, uint32_t csize, bool bck, const uint8_t* hist, size_t hist_len,
+                                                 uint8_t* dst, uint32_t dst_cap, bool linked, uint32_t block_size, uint32_t* decoded)
+{
+    ParsedHeader ph; memset(&ph, 0, sizeof(ph));
+    ph.max_block = block_size;
+    ph.info.blockMode = linked ? LZ4F_blockLinked : LZ4F_blockIndependent;
+    ph.info.blockChecksumFlag = bck ? LZ4F_blockChecksumEnabled : LZ4F_noBlockChecksum;
+    std::vector<lz4f_mi355x_block> e(1);
+    e[0].src_off = 0; e[0].dst_off = 0; e[0].word = csize; e[0].dst_size = dst_cap < block_size ? dst_cap : block_size;
+    size_t got = 0;
+    size_t r = run_decode_slab(payload, (size_t)csize + (bck ? 4 : 0), e, ph, hist, hist_len, dst, dst_cap, &got);
+    if (is_err(r)) return r;
+    *decoded = (uint32_t)got;
+    return 0;
+}
+
+size_t lz4f_mi355x_engine::decompress_frame_host(const uint8_t* s, size_t n, const ParsedHeader& ph, uint8_t* dst, size_t cap,
+                                                 size_t* decoded, size_t* consumed)
+{
+    const size_t SLAB_SRC = (size_t)256 << 20, SLAB_DST = (size_t)512 << 20;
+    const size_t crc = ph.info.blockChecksumFlag ? 4 : 0;
+    const bool linked = ph.info.blockMode == LZ4F_blockLinked;
+    auto rd32 = [&](size_t at) { return (uint32_t)s[at] | ((uint32_t)s[at + 1] << 8) | ((uint32_t)s[at + 2] << 16) | ((uint32_t)s[at + 3] << 24); };
+    size_t pos = ph.header_size, out = 0;
+    bool end = false;
+    std::vector<lz4f_mi355x_block> entries;
+    while (!end) {
+        entries.clear();
+        const size_t slab_src = pos; size_t prov = 0;
+        for (;;) {
+            if (n - pos < 4) return make_err(LZ4F_ERROR_frameHeader_incomplete);
+            const uint32_t w = rd32(pos);
+            if (w == 0) { end = true; break; }
+            const size_t csz = w & 0x7FFFFFFFu;
+            if (csz > ph.max_block) return make_err(LZ4F_ERROR_maxBlockSize_invalid);
+            if (n - pos - 4 < csz + crc) return make_err(LZ4F_ERROR_frameHeader_incomplete);
+            if (!entries.empty() && ((pos - slab_src) + 4 + csz + crc > SLAB_SRC || prov + ph.max_block > SLAB_DST)) break;
+            if (out + prov >= cap && !(csz == 0)) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
+            lz4f_mi355x_block e;
+            e.src_off = pos + 4 - slab_src; e.dst_off = prov; e.word = w;
+            e.dst_size = (uint32_t)std::min(ph.max_block, cap - out - prov);
+            entries.push_back(e);
+            pos += 4 + csz + crc; prov += ph.max_block;
+        }
+        if (!entries.empty()) {
+            size_t got = 0;
+            const size_t hl = linked ? std::min(out, (size_t)65536) : 0;
+            size_t r = run_decode_slab(s + slab_src, pos - slab_src, entries, ph, dst + out - hl, hl, dst + out, cap - out, &got);
+            if (is_err(r)) return r;
+            out += got;
+        }
+    }
+    pos += 4;                                                   // EndMark
+    if (ph.info.contentSize && ph.info.contentSize != out) return make_err(LZ4F_ERROR_frameSize_wrong);
+    if (ph.info.contentChecksumFlag) {
+        if (n - pos < 4) return make_err(LZ4F_ERROR_frameHeader_incomplete);
+        if (rd32(pos) != xxh32_host(dst, out)) return make_err(LZ4F_ERROR_contentChecksum_invalid);   // serial by construction: host
+        pos += 4;
+    }
+    *decoded = out; *consumed = pos;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: engine + device-pointer entry points
+extern "C" {
+
+const char* lz4f_mi355x_last_error(void) { return lz4f::last_error(); }
+
+int lz4f_mi355x_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+size_t lz4f_mi355x_set_device(int device)
+{
+    int n = lz4f_mi355x_device_count();
+    if (device < 0 || device >= n) { set_last_error("device %d out of range (%d devices)", device, n); return make_err(LZ4F_ERROR_GENERIC); }
+    if (lz4f::t_engine && lz4f::t_engine->device != device) { delete lz4f::t_engine; lz4f::t_engine = nullptr; }
+    lz4f::t_device = device;
+    return 0;
+}
+
+size_t lz4f_mi355x_engine_create(lz4f_mi355x_engine** out, int device, void* hipStream)
+{
+    if (!out) return make_err(LZ4F_ERROR_GENERIC);
+    return new_engine(out, device, hipStream);
+}
+size_t lz4f_mi355x_engine_free(lz4f_mi355x_engine* e) { delete e; return 0; }
+void* lz4f_mi355x_engine_stream(lz4f_mi355x_engine* e) { return e ? e->stream : nullptr; }
+
+size_t lz4f_mi355x_dev_workspace_size(size_t srcSize, const LZ4F_preferences_t* prefs)
+{
+    size_t bs = block_size_of(prefs ? prefs->frameInfo.blockSizeID : 0);
+    if (!bs) return make_err(LZ4F_ERROR_maxBlockSize_invalid);
+    uint32_t ch = pick_chunk_size((uint32_t)bs);
+    size_t nchunks = (srcSize + bs - 1) / bs * (bs / ch) + 1;
+    return nchunks * (sizeof(ChunkInfo) + (size_t)(ch / 4 + 1) * 8) + ((srcSize + bs - 1) / bs + 1) * (sizeof(BlockOut) + 4) + 4096;
+}
+
+size_t lz4f_mi355x_dev_compressFrame(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize,
+                                     const LZ4F_preferences_t* prefs, lz4f_mi355x_result* d_result, lz4f_mi355x_block* d_table)
+{
+    if (!e) return make_err(LZ4F_ERROR_GENERIC);
+    LZ4F_preferences_t p; memset(&p, 0, sizeof(p));
+    if (prefs) p = *prefs;
+    if (p.frameInfo.blockSizeID == 0) p.frameInfo.blockSizeID = LZ4F_max64KB;
+    const size_t bs = block_size_of(p.frameInfo.blockSizeID);
+    if (!bs) return make_err(LZ4F_ERROR_maxBlockSize_invalid);
+    if (p.frameInfo.contentChecksumFlag) { set_last_error("content checksum is host-only (serial XXH32): use lz4f_mi355x_compressFrame"); return make_err(LZ4F_ERROR_contentChecksumFlag_invalid); }
+    if (p.compressionLevel > 2) { set_last_error("only the fast encoder (level <= 2) exists"); return make_err(LZ4F_ERROR_compressionLevel_invalid); }
+    if (p.frameInfo.contentSize && p.frameInfo.contentSize != srcSize) return make_err(LZ4F_ERROR_frameSize_wrong);
+    lz4f_mi355x_engine::CompressJob j; memset(&j, 0, sizeof(j));
+    j.d_src = (const uint8_t*)d_src; j.src_size = srcSize; j.first_off = 0; j.block_size = (uint32_t)bs;
+    j.linked = p.frameInfo.blockMode == LZ4F_blockLinked; j.block_checksum = p.frameInfo.blockChecksumFlag != 0; j.endmark = true;
+    j.header_size = (uint32_t)write_frame_header(j.header, p);
+    return e->launch_compress(j, (uint8_t*)d_dst, dstCapacity, d_result, d_table);
+}
+
+size_t lz4f_mi355x_dev_decompressFrame(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_frame, size_t frameCapacity,
+                                       lz4f_mi355x_result* d_result)
+{
+    if (!e) return make_err(LZ4F_ERROR_GENERIC);
+    if (hipSetDevice(e->device) != hipSuccess) { set_last_error("hipSetDevice failed"); return make_err(LZ4F_ERROR_GENERIC); }
+    // the descriptor (7..19 bytes) decides block size / linked / checksum flags: peek it (the only host sync here)
+    uint8_t hdr[32]; memset(hdr, 0, sizeof(hdr));
+    const size_t peek = frameCapacity < 19 ? frameCapacity : 19;
+    if (peek < 7) return make_err(LZ4F_ERROR_frameHeader_incomplete);
+    if (hipMemcpyAsync(hdr, d_frame, peek, hipMemcpyDeviceToHost, (hipStream_t)e->stream) != hipSuccess ||
+        hipStreamSynchronize((hipStream_t)e->stream) != hipSuccess) { set_last_error("header peek failed"); return make_err(LZ4F_ERROR_GENERIC); }
+    lz4f_mi355x_engine::DecompressJob j; memset(&j, 0, sizeof(j));
+    j.d_frame = (const uint8_t*)d_frame; j.frame_cap = frameCapacity; j.d_dst = (uint8_t*)d_dst; j.dst_cap = dstCapacity; j.hist0 = 0;
+    j.block_size = 65536; j.linked = false; j.block_checksum = false; j.max_blocks = 1;
+    const uint32_t magic = (uint32_t)hdr[0] | (hdr[1] << 8) | (hdr[2] << 16) | ((uint32_t)hdr[3] << 24);
+    if (magic == 0x184D2204u) {
+        ParsedHeader ph;
+        size_t hs = parse_frame_header(hdr, peek, &ph);
+        if (is_err(hs)) return hs;
+        j.block_size = (uint32_t)ph.max_block; j.linked = ph.info.blockMode == LZ4F_blockLinked; j.block_checksum = ph.info.blockChecksumFlag != 0;
+        const uint64_t by_dst = dstCapacity / ph.max_block + 2;
+        const uint64_t by_src = frameCapacity / 5 + 2;                // every block costs at least 5 frame bytes
+        uint64_t mb = by_dst < by_src ? by_dst : by_src;
+        if (mb > 0x7FFFFFFFull) mb = 0x7FFFFFFFull;
+        j.max_blocks = (uint32_t)mb;
+    }
+    return e->launch_decompress(j, d_result);
+}
+
+size_t lz4f_mi355x_dev_decompressBlocks(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_frame, size_t frameCapacity,
+                                        const lz4f_mi355x_block* d_table, uint32_t n_blocks, const LZ4F_frameInfo_t* info,
+                                        lz4f_mi355x_result* d_result)
+{
+    if (!e || !d_table || !info) return make_err(LZ4F_ERROR_GENERIC);
+    const size_t bs = block_size_of(info->blockSizeID);
+    if (!bs) return make_err(LZ4F_ERROR_maxBlockSize_invalid);
+    lz4f_mi355x_engine::DecompressJob j; memset(&j, 0, sizeof(j));
+    j.d_frame = (const uint8_t*)d_frame; j.frame_cap = frameCapacity; j.d_dst = (uint8_t*)d_dst; j.dst_cap = dstCapacity; j.hist0 = 0;
+    j.block_size = (uint32_t)bs; j.linked = info->blockMode == LZ4F_blockLinked; j.block_checksum = info->blockChecksumFlag != 0;
+    j.d_table = d_table; j.n_blocks = n_blocks; j.max_blocks = n_blocks;
+    return e->launch_decompress(j, d_result);
+}
+
+size_t lz4f_mi355x_dev_xxh32(lz4f_mi355x_engine* e, const void* d_base, const uint64_t* d_off, const uint32_t* d_len, uint32_t n_blocks, uint32_t* d_out)
+{
+    if (!e) return make_err(LZ4F_ERROR_GENERIC);
+    if (hipSetDevice(e->device) != hipSuccess) { set_last_error("hipSetDevice failed"); return make_err(LZ4F_ERROR_GENERIC); }
+    if (n_blocks == 0) return 0;
+    constexpr int W = 4;
+    hipLaunchKernelGGL((k_xxh32_ranges<W>), dim3((n_blocks + W - 1) / W), dim3(64 * W), 0, (hipStream_t)e->stream, (const uint8_t*)d_base, d_off, d_len,
+                       n_blocks, d_out);
+    if (hipGetLastError() != hipSuccess) { set_last_error("xxh32 launch failed"); return make_err(LZ4F_ERROR_GENERIC); }
+    return 0;
+}
+
+}  // extern "C"

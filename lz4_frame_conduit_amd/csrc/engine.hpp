@@ -1,0 +1,104 @@
+// engine.hpp -- per-device engine: HIP stream, grow-only HBM workspace, kernel launch plumbing.
+// Host side of the product above the C ABI (C++, because the reference's host is compiled code).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/lz4f_mi355x.h"
+
+namespace lz4f {
+
+// ---- errors (LZ4F convention: (size_t)-code) ----
+inline size_t make_err(int code) { return (size_t)-(ptrdiff_t)code; }
+inline bool   is_err(size_t v) { return v > make_err(LZ4F_ERROR_maxCode); }
+const char*   err_name(size_t v);
+void          set_last_error(const char* fmt, ...);
+const char*   last_error();
+
+// ---- host XXH32 (header checksum byte; whole-stream content checksum, which is serial) ----
+struct Xxh32State {
+    uint32_t total_len, large, v[4], memsize;
+    uint8_t  mem[16];
+    void reset(uint32_t seed = 0);
+    void update(const void* data, size_t len);
+    uint32_t digest() const;
+};
+uint32_t xxh32_host(const void* data, size_t len, uint32_t seed = 0);
+
+// ---- frame header helpers (row a6; host side) ----
+size_t block_size_of(unsigned blockSizeID);                 // 0 when invalid
+size_t write_frame_header(uint8_t* dst, const LZ4F_preferences_t& p);      // p.frameInfo.blockSizeID already resolved
+size_t compress_bound_internal(size_t srcSize, const LZ4F_preferences_t* prefs, size_t alreadyBuffered);
+struct ParsedHeader { LZ4F_frameInfo_t info; size_t header_size; size_t max_block; };
+// LZ4F_decodeHeader semantics for a complete header at src (>= header size bytes available)
+size_t parse_frame_header(const uint8_t* src, size_t n, ParsedHeader* out);
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    int ensure(size_t n);          // grow-only hipMalloc; 0 on success
+    void release();
+};
+struct PinBuf {
+    void* p = nullptr; size_t cap = 0;
+    int ensure(size_t n);          // hipHostMalloc
+    void release();
+};
+
+}  // namespace lz4f
+
+struct lz4f_mi355x_engine {
+    int   device = 0;
+    void* stream = nullptr;        // hipStream_t
+    bool  own_stream = false;
+    lz4f::DevBuf info, recs, table, blk_bytes, res, bad;   // workspace of the block kernels
+    lz4f::DevBuf d_in, d_out;                              // staging for the host-pointer paths
+    lz4f::PinBuf h_in, h_out, h_small;
+
+    // ---- device-pointer paths (asynchronous on `stream`) ----
+    struct CompressJob {
+        const uint8_t* d_src; uint64_t src_size; uint64_t first_off;
+        uint32_t block_size; bool linked; bool block_checksum; bool endmark;
+        uint8_t header[20]; uint32_t header_size;
+    };
+    // returns 0 or an LZ4F error; d_res/d_table may be null (internal buffers are used)
+    size_t launch_compress(const CompressJob& j, uint8_t* d_dst, uint64_t dst_cap, lz4f_mi355x_result* d_res, lz4f_mi355x_block* d_table);
+    struct DecompressJob {
+        const uint8_t* d_frame; uint64_t frame_cap; uint8_t* d_dst; uint64_t dst_cap; uint64_t hist0;
+        uint32_t block_size; bool linked; bool block_checksum;
+        const lz4f_mi355x_block* d_table; uint32_t n_blocks;     // when d_table != null the walk is skipped
+        bool table_in_place;                                     // the engine's own table already holds n_blocks entries
+        uint32_t max_blocks;                                     // grid bound when walking
+    };
+    size_t launch_decompress(const DecompressJob& j, lz4f_mi355x_result* d_res);
+    size_t sync();
+
+    // ---- host-pointer helpers used by the streaming contexts and the bulk host calls ----
+    // Encode `n` bytes at src (host) as frame blocks of block_size (last may be short); `hist` bytes of
+    // history (host) precede them when linked.  Appends [size word][payload][checksum] per block to out.
+    size_t compress_blocks_host(const uint8_t* src, size_t n, const uint8_t* hist, size_t hist_len,
+                                uint32_t block_size, bool linked, bool block_checksum, std::vector<uint8_t>& out);
+    // Decode one compressed block payload (host; followed by its 4-byte checksum when bck) with `hist_len`
+    // bytes of history (host, linked frames).  The checksum is verified and the block decoded on the GPU;
+    // the decoded bytes land in dst (host).
+    size_t decompress_block_host(const uint8_t* payload, uint32_t csize, bool bck, const uint8_t* hist, size_t hist_len,
+                                 uint8_t* dst, uint32_t dst_cap, bool linked, uint32_t block_size, uint32_t* decoded);
+    // Whole frame (host) -> dst (host): host walk of the size words, then one device call per slab of blocks.
+    size_t decompress_frame_host(const uint8_t* frame, size_t n, const lz4f::ParsedHeader& ph, uint8_t* dst, size_t cap,
+                                 size_t* decoded, size_t* consumed);
+
+    ~lz4f_mi355x_engine();
+
+private:
+    size_t run_decode_slab(const uint8_t* frame_part, size_t part_len, const std::vector<lz4f_mi355x_block>& entries,
+                           const lz4f::ParsedHeader& ph, const uint8_t* hist, size_t hist_len, uint8_t* dst, size_t dst_room, size_t* got);
+};
+
+namespace lz4f {
+// engine bound to the calling thread's selected device; created on first use
+size_t thread_engine(lz4f_mi355x_engine** out);
+size_t new_engine(lz4f_mi355x_engine** out, int device, void* stream);
+int    selected_device();
+uint32_t pick_chunk_size(uint32_t block_size);
+}
