@@ -1,0 +1,191 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on MI355X: GiB/s end-to-end (compress+decompress), 4 MiB blocks.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched under torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident in
+HBM: compress the stream into one LZ4 frame (find_matches -> layout -> emit kernels), then decompress
+that frame (decode kernel driven by the block table the compressor produced), all through the C ABI
+(lz4f_mi355x_dev_compressFrame / lz4f_mi355x_dev_decompressBlocks) on torch's current stream.
+Workload at every N: BASELINE configs[2] per GPU -- 4 GiB of synth50 (~50 % compressible), 4 MiB
+independent blocks; frame blocks are independent, so ranks shard the stream with no data-path
+collective ("weak" scaling: every rank gets its own 4 GiB with seed 1234+rank).
+value = bytes of uncompressed input all ranks processed / max-over-ranks wall time of the K steps.
+
+Extra objects on the JSON line:
+  roofline     : the kernel with the largest share of the step, algorithmic bytes (U + C per direction,
+                 SURVEY.md section 8d) / its mean launch duration measured with HIP events on the launch stream
+  kernels      : the same for every kernel of the step
+  cpu_baseline : the same blocks through liblz4 (dlopen, kind "reference") or the oracle port, on the host cores,
+                 rank 0 at N=1 only, on a bounded sample
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GIB = float(1 << 30)
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_COPY_GBS = 6290.0
+
+
+def cpu_baseline(block_size: int, sample_bytes: int):
+    """oracle/orc_cpu_baseline on `sample_bytes` of the canonical (numpy) synth50 stream."""
+    import oracle
+    from lz4_frame_conduit_amd import datagen
+    oracle.build()
+    exe = os.path.join(ROOT, "oracle", "orc_cpu_baseline")
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    data = datagen.synth50(sample_bytes, 1234)
+    d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    path = os.path.join(d, "lz4f_bench_sample_%d.bin" % os.getpid())
+    try:
+        data.tofile(path)
+        out = subprocess.run([exe, path, str(block_size), str(cores), "3"], capture_output=True, text=True, timeout=600)
+        j = json.loads(out.stdout.strip().splitlines()[-1])
+    finally:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    u = j["bytes"]
+    e2e = u / (j["t_comp"] + j["t_decomp"]) / GIB
+    return {"value": round(e2e, 3), "unit": "GiB/s", "cores": j["threads"], "kind": j["kind"],
+            "sample": "%d MiB of synth50 (seed 1234), %d KiB independent blocks, block-parallel LZ4_compress_default + LZ4_decompress_safe, "
+                      "best of 3 after warm-up" % (u >> 20, block_size >> 10),
+            "compress_GiBs": round(u / j["t_comp"] / GIB, 3), "decompress_GiBs": round(u / j["t_decomp"] / GIB, 3),
+            "ratio": round(u / j["compressed"], 4), "roundtrip_ok": j["roundtrip_ok"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--bytes", type=int, default=4 << 30, help="uncompressed bytes per GPU per step")
+    ap.add_argument("--block-size-id", type=int, default=7, help="4=64KiB 5=256KiB 6=1MiB 7=4MiB")
+    ap.add_argument("--block-checksum", type=int, default=0)
+    ap.add_argument("--linked", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-mib", type=int, default=512)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from lz4_frame_conduit_amd import conduit
+    from lz4_frame_conduit_amd.device import Engine, synth50_device
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+
+    n = args.bytes
+    bs = 1 << (8 + 2 * args.block_size_id)
+    prefs = conduit.make_preferences(blockSizeID=args.block_size_id, blockMode=0 if args.linked else 1, blockChecksum=args.block_checksum)
+    nb = (n + bs - 1) // bs
+
+    src = synth50_device(n, 1234 + rank, dev)
+    eng = Engine(local_rank)
+    frame = torch.empty(eng.frame_bound(n, prefs), dtype=torch.uint8, device=dev)
+    back = torch.empty_like(src)
+    table = eng.new_table(nb)
+    eng.set_timing(True)
+
+    def step():
+        eng.compress_async(src, frame, prefs, table)
+        # frame size is known on the device only; the decoder needs just an upper bound for bounds checks
+        eng.decompress_blocks_async(frame, frame.numel(), back, table, nb, prefs.frameInfo)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    eng.compress_async(src, frame, prefs, table)
+    r = eng.result()
+    csize = int(r.size)
+
+    kt = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        if rank == 0:
+            # get_timing synchronises the stream; the same sync would be paid by the next step's barrier anyway
+            for k, v in eng.get_timing().items():
+                kt.setdefault(k, []).append(v)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    r2 = eng.result()
+    ok = bool(r2.size == n and torch.equal(back, src))
+
+    if rank == 0:
+        total_u = n * world * args.steps
+        value = total_u / dt / GIB
+        mean = {k: (sum(v) / len(v)) for k, v in kt.items() if v and sum(v) > 0}
+        algo = float(n + csize)               # U + C per direction; match copies served on-chip are not counted
+        kernels = {k: {"ms": round(ms, 4), "algo_GBs": round(algo / (ms * 1e-3) / 1e9, 1)} for k, ms in mean.items() if k in ("find_matches", "emit", "decode")}
+        dom = max(kernels, key=lambda k: kernels[k]["ms"]) if kernels else None
+        t_comp = sum(mean.get(k, 0.0) for k in ("find_matches", "layout", "emit", "xxh32_write"))
+        t_dec = sum(mean.get(k, 0.0) for k in ("walk", "xxh32_verify", "decode", "finish"))
+        out = {
+            "metric": "GiB/s end-to-end (compress+decompress), 4 MiB blocks, 1/2/4/8 GPUs vs liblz4",
+            "value": round(value, 3), "unit": "GiB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "synth50 (~50%% compressible), %.0f GiB per GPU per step, %d KiB %s blocks, device-resident (inputs/outputs in HBM), "
+                                   "block checksums %s, content checksum off" % (n / GIB, bs >> 10, "linked" if args.linked else "independent",
+                                                                                "on" if args.block_checksum else "off"),
+                       "bytes_per_gpu": n, "block_size": bs, "n_blocks_per_gpu": nb, "generator": "synth50 recipe, torch Philox seed 1234+rank",
+                       "sharding": "one 4 GiB stream per rank, no collective" if world > 1 else "single GPU"},
+            "ratio": round(n / csize, 4), "compressed_bytes": csize, "roundtrip_verified": ok,
+            "compress_GiBs_per_gpu": round(n / (t_comp * 1e-3) / GIB, 2) if t_comp else None,
+            "decompress_GiBs_per_gpu": round(n / (t_dec * 1e-3) / GIB, 2) if t_dec else None,
+            "kernels": kernels,
+        }
+        if dom:
+            a = kernels[dom]["algo_GBs"]
+            out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
+                               "traffic": None, "algorithmic_bytes_per_launch": int(algo), "ms_per_launch": kernels[dom]["ms"],
+                               "frac_of_measured_copy_peak": round(a / HBM_COPY_GBS, 4)}
+            if "decode" in kernels:
+                d = kernels["decode"]["algo_GBs"]
+                out["roofline_decode"] = {"bound": "hbm", "achieved": d, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d / HBM_PEAK_GBS, 4)}
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(bs, args.cpu_sample_mib << 20)
+            except Exception as e:  # the baseline is a reported reference point, never a reason to lose the GPU number
+                out["cpu_baseline"] = {"value": None, "unit": "GiB/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        print(json.dumps(out))
+    eng.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

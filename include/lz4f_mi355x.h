@@ -171,10 +171,19 @@ LZ4F_MI355X_API size_t lz4f_mi355x_decompressFrame(void* dst, size_t dstCapacity
 /* ---- device-resident engine: everything stays in HBM, nothing synchronises with the host ---- */
 typedef struct lz4f_mi355x_engine lz4f_mi355x_engine;
 
-/* `hipStream` is a hipStream_t (NULL = the engine creates its own stream on `device`). */
-LZ4F_MI355X_API size_t lz4f_mi355x_engine_create(lz4f_mi355x_engine** out, int device, void* hipStream);
+/* borrowStream == 0: the engine creates (and owns) a non-blocking stream on `device`; hipStream is ignored.
+ * borrowStream != 0: all work is enqueued on the caller's hipStream_t `hipStream` (NULL = HIP's default stream). */
+LZ4F_MI355X_API size_t lz4f_mi355x_engine_create(lz4f_mi355x_engine** out, int device, void* hipStream, int borrowStream);
 LZ4F_MI355X_API size_t lz4f_mi355x_engine_free(lz4f_mi355x_engine* e);
 LZ4F_MI355X_API void*  lz4f_mi355x_engine_stream(lz4f_mi355x_engine* e);
+
+/* Optional per-kernel timing with HIP events recorded on the engine's stream around each kernel of the last
+ * compress / decompress call.  get_timing synchronises the stream and fills ms[] (milliseconds):
+ *   [0] find_matches  [1] layout  [2] emit  [3] xxh32 (compress)  [4] walk  [5] xxh32 (verify)  [6] decode  [7] finish
+ * entries of kernels that did not run are 0. */
+#define LZ4F_MI355X_TIMING_SLOTS 8
+LZ4F_MI355X_API size_t lz4f_mi355x_engine_set_timing(lz4f_mi355x_engine* e, int enable);
+LZ4F_MI355X_API size_t lz4f_mi355x_engine_get_timing(lz4f_mi355x_engine* e, float* ms);
 
 /* result record the device writes; read it back after synchronising the stream */
 typedef struct {

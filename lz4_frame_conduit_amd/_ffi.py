@@ -64,8 +64,9 @@ _SIGS = {
     "lz4f_mi355x_compressFrameBound": (c_size_t, [c_size_t, PP]),
     "lz4f_mi355x_compressFrame": (c_size_t, [c_void_p, c_size_t, c_void_p, c_size_t, PP]),
     "lz4f_mi355x_decompressFrame": (c_size_t, [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]),
-    "lz4f_mi355x_engine_create": (c_size_t, [ctypes.POINTER(c_void_p), ctypes.c_int, c_void_p]), "lz4f_mi355x_engine_free": (c_size_t, [c_void_p]),
-    "lz4f_mi355x_engine_stream": (c_void_p, [c_void_p]), "lz4f_mi355x_dev_workspace_size": (c_size_t, [c_size_t, PP]),
+    "lz4f_mi355x_engine_create": (c_size_t, [ctypes.POINTER(c_void_p), ctypes.c_int, c_void_p, ctypes.c_int]), "lz4f_mi355x_engine_free": (c_size_t, [c_void_p]),
+    "lz4f_mi355x_engine_stream": (c_void_p, [c_void_p]),
+    "lz4f_mi355x_engine_set_timing": (c_size_t, [c_void_p, ctypes.c_int]), "lz4f_mi355x_engine_get_timing": (c_size_t, [c_void_p, ctypes.POINTER(ctypes.c_float)]), "lz4f_mi355x_dev_workspace_size": (c_size_t, [c_size_t, PP]),
     "lz4f_mi355x_dev_compressFrame": (c_size_t, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, PP, c_void_p, c_void_p]),
     "lz4f_mi355x_dev_decompressFrame": (c_size_t, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "lz4f_mi355x_dev_decompressBlocks": (c_size_t, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, ctypes.c_uint32, ctypes.POINTER(FrameInfo), c_void_p]),
@@ -90,11 +91,28 @@ def build(force: bool = False) -> str:
     return LIB_PATH
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch wheels bundle their own libamdhip64.so (soname libamdhip64.so.7, the same soname as
+    /opt/rocm's).  Two HIP runtimes in one process fight over the device ("no ROCm-capable device"),
+    so when torch is installed its copy is mapped first and liblz4f_mi355x.so binds to it by soname.
+    A non-Python host (the Haskell conduit) simply gets /opt/rocm's runtime through the RUNPATH."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            p = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(p):
+                ctypes.CDLL(p, mode=ctypes.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     global _LIB
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("liblz4f_mi355x.so is not built (run __graft_entry__.build()); there is no CPU fallback")
+        _share_hip_runtime_with_torch()
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             f = getattr(L, name)          # AttributeError = a declared symbol is not exported

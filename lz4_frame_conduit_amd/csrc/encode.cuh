@@ -53,6 +53,7 @@ struct EncGeom {
     uint32_t header_size;
     uint8_t  header[20];
     uint32_t max_rec_per_chunk;  // record slots per chunk
+    uint32_t seed_stride, seed_dense;   // table pre-seed: every seed_stride-th position, last seed_dense bytes densely
 };
 
 __device__ __forceinline__ uint32_t len_ext_bytes(uint32_t v) { return v >= 15 ? (v - 15) / 255 + 1 : 0; }
@@ -106,11 +107,21 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
     const uint32_t bend = back + (uint32_t)(bend_abs - cs_abs);
     uint64_t* rec = recs + (uint64_t)chunk * g.max_rec_per_chunk;
 
-    // clear + pre-seed the table with the history in front of the chunk
+    // clear + pre-seed the table with the history in front of the chunk.  A 4096-entry table cannot hold
+    // 64 KiB of positions, and later inserts win: seed the whole window sparsely (every SEED_STRIDE-th position,
+    // roughly the density the skip-accelerated search itself leaves behind), then the last SEED_DENSE bytes densely.
     for (uint32_t i = lane; i < HASH_SIZE / 2; i += WAVE) ((uint32_t*)table)[i] = 0;
-    for (uint32_t q = 0; q + 4 <= back; q += WAVE) {
-        const uint32_t p = q + lane;
-        if (p + 4 <= back) table[(ld32(base + p) * 2654435761u) >> (32 - HASH_LOG)] = (uint16_t)p;
+    if (back >= 4) {
+        const uint32_t dense_from = back > g.seed_dense ? back - g.seed_dense : 0;
+        const uint32_t ss = g.seed_stride;
+        for (uint32_t q = 0; q < dense_from; q += WAVE * ss) {
+            const uint32_t p = q + lane * ss;
+            if (p < dense_from) table[(ld32(base + p) * 2654435761u) >> (32 - HASH_LOG)] = (uint16_t)p;
+        }
+        for (uint32_t q = dense_from; q + 4 <= back; q += WAVE) {
+            const uint32_t p = q + lane;
+            if (p + 4 <= back) table[(ld32(base + p) * 2654435761u) >> (32 - HASH_LOG)] = (uint16_t)p;
+        }
     }
 
     uint32_t nrec = 0, first_lit = 0, body = 0;
@@ -136,15 +147,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
                 h = (seq * 2654435761u) >> (32 - HASH_LOG);
                 e = table[h];
             }
-            // all probes of this step read the table before any of them writes it
-            __builtin_amdgcn_wave_barrier();
-            if (act) table[h] = (uint16_t)p;
             const uint32_t d = (p - e) & 0xFFFFu;
             const bool ok = act && d != 0 && d <= p;
             const uint32_t cand = p - d;
             uint32_t cseq = ~seq;
             if (ok) cseq = ld32(base + cand);
             const uint64_t hits = __ballot(ok && cseq == seq);
+            // insert only the positions the greedy parse really visits (up to and including the first hit):
+            // later lanes will be probed again from the end of the match and must not find themselves
+            const uint32_t L64 = hits ? (uint32_t)__builtin_ctzll(hits) : WAVE;
+            if (act && lane <= L64) table[h] = (uint16_t)p;
             if (hits == 0) {
                 ip += WAVE * step;
                 step += 1;
@@ -191,6 +203,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
             nrec++;
             anchor = ip = mp + mlen;
             step = 1;
+            if (lane == 0 && ip >= 2 + cs && ip + 2 <= ce) {          // like the CPU encoder: also index ip-2
+                const uint32_t q = ip - 2;
+                table[(ld32(base + q) * 2654435761u) >> (32 - HASH_LOG)] = (uint16_t)q;
+            }
             if (nrec >= g.max_rec_per_chunk) break;          // cannot happen with ceil(chunk/4) slots; belt and braces
         }
     }

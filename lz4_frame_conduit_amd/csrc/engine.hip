@@ -77,7 +77,7 @@ uint32_t pick_chunk_size(uint32_t block_size)
     return block_size < c ? block_size : c;
 }
 
-size_t new_engine(lz4f_mi355x_engine** out, int device, void* stream)
+size_t new_engine(lz4f_mi355x_engine** out, int device, void* stream, bool borrow)
 {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -89,7 +89,7 @@ size_t new_engine(lz4f_mi355x_engine** out, int device, void* stream)
     HIP_TRY(hipSetDevice(device));
     lz4f_mi355x_engine* en = new lz4f_mi355x_engine();
     en->device = device;
-    if (stream) { en->stream = stream; en->own_stream = false; }
+    if (borrow) { en->stream = stream; en->own_stream = false; }
     else {
         hipStream_t s;
         hipError_t e2 = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
@@ -103,7 +103,7 @@ size_t new_engine(lz4f_mi355x_engine** out, int device, void* stream)
 size_t thread_engine(lz4f_mi355x_engine** out)
 {
     if (!t_engine) {
-        size_t r = new_engine(&t_engine, selected_device(), nullptr);
+        size_t r = new_engine(&t_engine, selected_device(), nullptr, false);
         if (is_err(r)) { t_engine = nullptr; return r; }
     }
     *out = t_engine;
@@ -115,11 +115,21 @@ size_t thread_engine(lz4f_mi355x_engine** out)
 lz4f_mi355x_engine::~lz4f_mi355x_engine()
 {
     (void)hipSetDevice(device);
-    if (stream) (void)hipStreamSynchronize((hipStream_t)stream);
+    (void)hipStreamSynchronize((hipStream_t)stream);
     info.release(); recs.release(); table.release(); blk_bytes.release(); res.release(); bad.release();
     d_in.release(); d_out.release();
     h_in.release(); h_out.release(); h_small.release();
+    for (int i = 0; i < 16; i++) if (ev[i]) (void)hipEventDestroy((hipEvent_t)ev[i]);
     if (own_stream && stream) (void)hipStreamDestroy((hipStream_t)stream);
+}
+
+void lz4f_mi355x_engine::tick(int slot, bool end)
+{
+    if (!timing) return;
+    const int i = slot * 2 + (end ? 1 : 0);
+    if (!ev[i]) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; ev[i] = e; }
+    (void)hipEventRecord((hipEvent_t)ev[i], (hipStream_t)stream);
+    if (end) ev_used[slot] = true;
 }
 
 size_t lz4f_mi355x_engine::sync()
@@ -148,6 +158,8 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     g.linked = j.linked; g.block_checksum = j.block_checksum;
     g.header_size = j.header_size; memcpy(g.header, j.header, j.header_size);
     g.max_rec_per_chunk = g.chunk_size / 4 + 1;
+    g.seed_stride = 4; g.seed_dense = 1024;
+    if (const char* sv = getenv("LZ4F_MI355X_SEED")) { unsigned a = 0, b = 0; if (sscanf(sv, "%u,%u", &a, &b) == 2 && a >= 1) { g.seed_stride = a; g.seed_dense = b; } }
 
     if (info.ensure((size_t)(g.n_chunks + 1) * sizeof(ChunkInfo))) return make_err(LZ4F_ERROR_allocation_failed);
     if (recs.ensure((size_t)(g.n_chunks + 1) * g.max_rec_per_chunk * 8)) return make_err(LZ4F_ERROR_allocation_failed);
@@ -156,18 +168,28 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     if (!d_res) { if (res.ensure(sizeof(ResultRec))) return make_err(LZ4F_ERROR_allocation_failed); d_res = (lz4f_mi355x_result*)res.p; }
 
     constexpr int W = 4;
+    for (int i = 0; i < 4; i++) ev_used[i] = false;
     if (g.n_chunks) {
+        tick(0, false);
         hipLaunchKernelGGL((k_find_matches<W>), dim3((g.n_chunks + W - 1) / W), dim3(64 * W), 0, st, j.d_src, g,
                            (ChunkInfo*)info.p, (uint64_t*)recs.p);
+        tick(0, true);
     }
+    tick(1, false);
     hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, g, (ChunkInfo*)info.p, (BlockOut*)d_table, (uint32_t*)blk_bytes.p,
                        d_dst, dst_cap, (ResultRec*)d_res);
+    tick(1, true);
     if (g.n_chunks) {
+        tick(2, false);
         hipLaunchKernelGGL((k_emit<W>), dim3((g.n_chunks + W - 1) / W), dim3(64 * W), 0, st, j.d_src, g, (const ChunkInfo*)info.p,
                            (const uint64_t*)recs.p, d_dst);
-        if (j.block_checksum)
+        tick(2, true);
+        if (j.block_checksum) {
+            tick(3, false);
             hipLaunchKernelGGL((k_xxh32_blocks<W>), dim3((g.n_blocks + W - 1) / W), dim3(64 * W), 0, st, d_dst, (BlockOut*)d_table,
                                (const ResultRec*)d_res, g.n_blocks, 0u, (uint32_t*)nullptr);
+            tick(3, true);
+        }
     }
     HIP_TRY(hipGetLastError());
     return 0;
@@ -193,20 +215,30 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         n_max = j.max_blocks;
         if (table.ensure((size_t)(n_max + 1) * sizeof(BlockOut))) return make_err(LZ4F_ERROR_allocation_failed);
         tbl = (BlockOut*)table.p;
+        tick(4, false);
         hipLaunchKernelGGL(k_walk_frame, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, j.dst_cap, tbl, n_max, (ResultRec*)d_res);
+        tick(4, true);
     }
     HIP_TRY(hipMemsetAsync(bad.p, 0xFF, 4, st));
+    for (int i = 4; i < 8; i++) ev_used[i] = false;
     constexpr int W = 4;
     const uint32_t grid = j.linked ? 1u : (n_max + W - 1) / W;
     if (n_max) {
-        if (j.block_checksum)
+        if (j.block_checksum) {
+            tick(5, false);
             hipLaunchKernelGGL((k_xxh32_blocks<W>), dim3((n_max + W - 1) / W), dim3(64 * W), 0, st, (uint8_t*)j.d_frame, tbl,
                                (const ResultRec*)d_res, n_max, 1u, (uint32_t*)bad.p);
+            tick(5, true);
+        }
+        tick(6, false);
         hipLaunchKernelGGL((k_decode_blocks<W>), dim3(grid), dim3(64 * W), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl, (const ResultRec*)d_res,
                            n_max, j.linked ? 1u : 0u, j.block_size, j.hist0);
+        tick(6, true);
     }
+    tick(7, false);
     hipLaunchKernelGGL(k_finish_decode, dim3(1), dim3(64), 0, st, j.d_dst, tbl, (ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size,
                        j.block_checksum ? (const uint32_t*)bad.p : (const uint32_t*)nullptr);
+    tick(7, true);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -372,13 +404,34 @@ size_t lz4f_mi355x_set_device(int device)
     return 0;
 }
 
-size_t lz4f_mi355x_engine_create(lz4f_mi355x_engine** out, int device, void* hipStream)
+size_t lz4f_mi355x_engine_create(lz4f_mi355x_engine** out, int device, void* hipStream, int borrowStream)
 {
     if (!out) return make_err(LZ4F_ERROR_GENERIC);
-    return new_engine(out, device, hipStream);
+    return new_engine(out, device, hipStream, borrowStream != 0);
 }
 size_t lz4f_mi355x_engine_free(lz4f_mi355x_engine* e) { delete e; return 0; }
 void* lz4f_mi355x_engine_stream(lz4f_mi355x_engine* e) { return e ? e->stream : nullptr; }
+
+size_t lz4f_mi355x_engine_set_timing(lz4f_mi355x_engine* e, int enable)
+{
+    if (!e) return make_err(LZ4F_ERROR_GENERIC);
+    e->timing = enable != 0;
+    return 0;
+}
+size_t lz4f_mi355x_engine_get_timing(lz4f_mi355x_engine* e, float* ms)
+{
+    if (!e || !ms) return make_err(LZ4F_ERROR_GENERIC);
+    size_t r = e->sync();
+    if (is_err(r)) return r;
+    for (int s = 0; s < LZ4F_MI355X_TIMING_SLOTS; s++) {
+        ms[s] = 0.f;
+        if (e->ev_used[s] && e->ev[2 * s] && e->ev[2 * s + 1]) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, (hipEvent_t)e->ev[2 * s], (hipEvent_t)e->ev[2 * s + 1]) == hipSuccess) ms[s] = t;
+        }
+    }
+    return 0;
+}
 
 size_t lz4f_mi355x_dev_workspace_size(size_t srcSize, const LZ4F_preferences_t* prefs)
 {

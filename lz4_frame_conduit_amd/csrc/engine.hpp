@@ -55,6 +55,10 @@ struct lz4f_mi355x_engine {
     lz4f::DevBuf info, recs, table, blk_bytes, res, bad;   // workspace of the block kernels
     lz4f::DevBuf d_in, d_out;                              // staging for the host-pointer paths
     lz4f::PinBuf h_in, h_out, h_small;
+    bool  timing = false;
+    void* ev[16] = {nullptr};      // hipEvent_t pairs (begin,end) per timing slot
+    bool  ev_used[8] = {false};
+    void  tick(int slot, bool end);
 
     // ---- device-pointer paths (asynchronous on `stream`) ----
     struct CompressJob {
@@ -98,7 +102,7 @@ private:
 namespace lz4f {
 // engine bound to the calling thread's selected device; created on first use
 size_t thread_engine(lz4f_mi355x_engine** out);
-size_t new_engine(lz4f_mi355x_engine** out, int device, void* stream);
+size_t new_engine(lz4f_mi355x_engine** out, int device, void* stream, bool borrow);
 int    selected_device();
 uint32_t pick_chunk_size(uint32_t block_size);
 }

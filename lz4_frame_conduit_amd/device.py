@@ -31,7 +31,7 @@ class Engine:
         torch.cuda.set_device(device)
         self.stream = stream if stream is not None else torch.cuda.current_stream(device)
         h = ctypes.c_void_p()
-        _chk(self.L, self.L.lz4f_mi355x_engine_create(ctypes.byref(h), device, ctypes.c_void_p(self.stream.cuda_stream)))
+        _chk(self.L, self.L.lz4f_mi355x_engine_create(ctypes.byref(h), device, ctypes.c_void_p(self.stream.cuda_stream), 1))
         self.h = h
         self._res = torch.zeros(32, dtype=torch.uint8, device="cuda:%d" % device)
 
@@ -45,6 +45,16 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    TIMING_SLOTS = ("find_matches", "layout", "emit", "xxh32_write", "walk", "xxh32_verify", "decode", "finish")
+
+    def set_timing(self, on: bool):
+        _chk(self.L, self.L.lz4f_mi355x_engine_set_timing(self.h, 1 if on else 0))
+
+    def get_timing(self) -> dict:
+        ms = (ctypes.c_float * 8)()
+        _chk(self.L, self.L.lz4f_mi355x_engine_get_timing(self.h, ms))
+        return dict(zip(self.TIMING_SLOTS, [float(x) for x in ms]))
 
     # -- helpers
     def _result(self) -> Result:

@@ -154,5 +154,5 @@ def test_no_gpu_fails_loudly(L):
         conduit.compress([b"x" * 70000])
     assert b"no usable HIP device" in L.lz4f_mi355x_last_error()
     h = ctypes.c_void_p()
-    r = L.lz4f_mi355x_engine_create(ctypes.byref(h), 0, None)
+    r = L.lz4f_mi355x_engine_create(ctypes.byref(h), 0, None, 0)
     assert L.LZ4F_isError(r)
