@@ -42,6 +42,7 @@ def cpu_baseline(block_size: int, sample_bytes: int):
     oracle.build()
     exe = os.path.join(ROOT, "oracle", "orc_cpu_baseline")
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, int(os.environ.get("LZ4F_BENCH_CPU_THREADS", "16"))))   # a 1-GPU box's CPU share is 16 cores
     data = datagen.synth50(sample_bytes, 1234)
     d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
     path = os.path.join(d, "lz4f_bench_sample_%d.bin" % os.getpid())
