@@ -179,9 +179,10 @@ LZ4F_MI355X_API void*  lz4f_mi355x_engine_stream(lz4f_mi355x_engine* e);
 
 /* Optional per-kernel timing with HIP events recorded on the engine's stream around each kernel of the last
  * compress / decompress call.  get_timing synchronises the stream and fills ms[] (milliseconds):
- *   [0] find_matches  [1] layout  [2] emit  [3] xxh32 (compress)  [4] walk  [5] xxh32 (verify)  [6] decode  [7] finish
+ *   [0] find_matches  [1] layout  [2] emit  [3] xxh32 (compress)  [4] walk  [5] xxh32 (verify)  [6] decode (all kernels)
+ *   [7] finish  [8] decode: parse kernel  [9] decode: copy kernel
  * entries of kernels that did not run are 0. */
-#define LZ4F_MI355X_TIMING_SLOTS 8
+#define LZ4F_MI355X_TIMING_SLOTS 10
 LZ4F_MI355X_API size_t lz4f_mi355x_engine_set_timing(lz4f_mi355x_engine* e, int enable);
 LZ4F_MI355X_API size_t lz4f_mi355x_engine_get_timing(lz4f_mi355x_engine* e, float* ms);
 

@@ -27,6 +27,16 @@ __device__ __forceinline__ uint64_t uni64(uint64_t v)
 // status codes written by kernels (values of LZ4F_errorCodes that can arise on the device)
 enum : uint32_t { ST_OK = 0, ST_GENERIC = 1, ST_MAXBLOCK = 2, ST_BLOCKCK = 7, ST_DSTSMALL = 11, ST_DECOMP = 16 };
 
+// ---- records shared with the host (include/lz4f_mi355x.h) ----
+struct BlockOut {            // mirrors lz4f_mi355x_block
+    uint64_t src_off, dst_off;
+    uint32_t word, dst_size;
+};
+struct ResultRec {           // mirrors lz4f_mi355x_result
+    uint64_t size, consumed;
+    uint32_t status, n_blocks, first_bad_block, flags;
+};
+
 // ---- XXH32 constants ----
 constexpr uint32_t XP1 = 2654435761u, XP2 = 2246822519u, XP3 = 3266489917u, XP4 = 668265263u, XP5 = 374761393u;
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }

@@ -1,0 +1,312 @@
+// decode_2k.cuh -- two-kernel LZ4 block decode for large blocks.
+//
+// At 4 MiB blocks a 4 GiB stream has only 1024 independent blocks (4 per CU).  The sequence PARSE of a
+// block is one serial dependent chain; the COPIES are where the bytes are.  So they are separate kernels:
+//
+//   k_parse_blocks   one WAVE per block, everything wave-uniform (SALU).  The payload streams through two
+//                    16 KiB LDS stages per wave, filled by direct-to-LDS loads (global_load_lds_dwordx4,
+//                    1 KiB per instruction) one stage AHEAD of the parser, so the chain
+//                    token -> lengths -> next token never waits on HBM: one 8-byte LDS read per sequence.
+//                    Output: one 16-byte descriptor per sequence {lit_src, lit_len, dst, match_len, offset},
+//                    gathered 64 at a time in VGPR lanes (v_cndmask on lane == slot) and stored as one coalesced 1 KiB write.
+//   k_copy_blocks    one WORKGROUP (8 waves) per block walks the descriptors in batches of 512:
+//                    literals (no dependencies at all) are copied HBM -> HBM 16 B per lane by all waves; a
+//                    match is "safe" when its source does not overlap the destination of an earlier match of
+//                    the same batch (one lane per sequence, binary search in LDS) and all safe matches are
+//                    copied in parallel; the rest are replayed in stream order by one wave.
+// Both kernels enforce the accept/reject rules of wave_decode_block (decode.cuh) / the oracle.
+#pragma once
+#include "common.cuh"
+#include "decode.cuh"
+
+namespace lz4f {
+
+constexpr uint32_t PK_STAGE = 16384;            // payload bytes per LDS stage
+constexpr uint32_t PK_OVER = 64;                // stages overlap: an 8-byte header read never straddles a stage end
+constexpr int      PK_WAVES = 4;                // parser waves (= blocks) per workgroup: 4 x 2 x 16.06 KiB = 128.5 KiB LDS
+constexpr int      CK_WAVES = 8;                // copy kernel: waves per workgroup
+constexpr int      CK_NB = 512;                 // descriptors per batch (one per thread)
+
+// descriptor: x = lit_src | off[7:0] << 24, y = lit_len | off[15:8] << 24, z = dst, w = match_len (0: last sequence)
+// (positions and lengths are < 2^23 because a block holds at most 4 MiB)
+struct SeqDesc { uint32_t x, y, z, w; };
+
+__device__ __forceinline__ uint32_t max_seq_per_block(uint32_t block_size) { return block_size / 4 + 2; }
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// issue the direct-to-LDS loads of payload bytes [s*STAGE, min(csize, (s+1)*STAGE + OVER)) into `slot`
+__device__ __forceinline__ void pk_stage_issue(uint8_t* slot, const uint8_t* __restrict__ in, uint32_t csize, uint32_t s)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t base = s * PK_STAGE;
+    if (base >= csize) return;
+    const uint32_t end = (base + PK_STAGE + PK_OVER < csize) ? base + PK_STAGE + PK_OVER : csize;
+    const uint32_t span = end - base;
+    for (uint32_t piece = 0; piece < span; piece += 1024) {
+        const uint32_t o = piece + lane * 16;
+        if (o + 16 <= span) __builtin_amdgcn_global_load_lds((gptr_t)(in + base + o), (lptr_t)(slot + piece), 16, 0, 0);
+    }
+    const uint32_t tail0 = span & ~15u;                          // ragged tail (< 16 B): bytewise, never past the payload
+    if (lane < span - tail0) slot[tail0 + lane] = in[base + tail0 + lane];
+}
+
+// 8 payload bytes at position q from the stage slots (all operands wave-uniform)
+__device__ __forceinline__ uint64_t pk_fetch8(const uint8_t* stages /* [2][STAGE+OVER] */, uint32_t q)
+{
+    const uint32_t s = q / PK_STAGE;
+    const uint32_t o = q - s * PK_STAGE;
+    const uint32_t* w = (const uint32_t*)(stages + (s & 1) * (PK_STAGE + PK_OVER));
+    const uint32_t i = o >> 2;
+    const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2];
+    const uint32_t shv = (o & 3u) * 8;
+    uint64_t v = (((uint64_t)w1 << 32) | w0) >> shv;
+    if (shv) v |= (uint64_t)w2 << (64 - shv);
+    return uni64(v);
+}
+
+// ------------------------------- kernel 1: parse -------------------------------------------------
+// seq_count[b] = number of descriptors of block b, or 0xFFFFFFFF when the block is malformed;
+// out_size[b]  = decoded size implied by the sequences.
+__global__ __launch_bounds__(64 * PK_WAVES) void k_parse_blocks(const uint8_t* __restrict__ frame, const BlockOut* __restrict__ table,
+                                                                const ResultRec* __restrict__ res, uint32_t n_max, uint32_t block_size, uint32_t linked,
+                                                                SeqDesc* __restrict__ desc, uint32_t* __restrict__ seq_count, uint32_t* __restrict__ out_size)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[PK_WAVES][2][PK_STAGE + PK_OVER];
+    if (res->status != ST_OK) return;
+    const uint32_t n_blocks = res->n_blocks < n_max ? res->n_blocks : n_max;
+    const uint32_t wave = uni(threadIdx.x >> 6), lane = lane_id();
+    const uint32_t blk = uni(blockIdx.x * PK_WAVES + wave);
+    if (blk >= n_blocks) return;
+    const BlockOut e = table[blk];
+    if (e.word >> 31) { if (lane == 0) { seq_count[blk] = 0; out_size[blk] = e.word & 0x7FFFFFFFu; } return; }   // stored block: nothing to parse
+    const uint32_t csize = e.word & 0x7FFFFFFFu;
+    const uint32_t cap = linked ? block_size : e.dst_size;       // linked frames: exact room is checked by the copy kernel
+    const uint8_t* __restrict__ in = frame + e.src_off;
+    uint8_t* stages = &s_stage[wave][0][0];
+    SeqDesc* dout = desc + (uint64_t)blk * max_seq_per_block(block_size);
+    const uint32_t dcap = max_seq_per_block(block_size);
+
+    uint32_t nseq = 0, status = 0;
+    uint32_t q = 0, op = 0;                      // payload cursor / output cursor
+    uint64_t w = 0; uint32_t avail = 0;          // w holds the next `avail` payload bytes at q
+    int32_t  cur = -1;                           // stage the parser is reading (resident)
+    bool     next_issued = false;                // stage cur+1 has been requested into the other slot
+    uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;     // 64 descriptors gathered across the lanes
+
+    if (csize == 0) status = 1;
+    else { pk_stage_issue(stages, in, csize, 0); next_issued = true; }
+    // make the stage that holds position qq readable.  Common case: still the current stage.  Next stage: wait for
+    // the loads issued one stage ago, then immediately request the one after it over the slot that just died.
+    auto need = [&](uint32_t qq) {
+        const int32_t s = (int32_t)(qq / PK_STAGE);
+        if (s == cur) return;
+        if (!(s == cur + 1 && next_issued)) {                                    // a jump (long literal run): load it now
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // never refill a slot that is still being filled
+            pk_stage_issue(stages + (uint32_t)(s & 1) * (PK_STAGE + PK_OVER), in, csize, (uint32_t)s);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cur = s;
+        pk_stage_issue(stages + (uint32_t)((s + 1) & 1) * (PK_STAGE + PK_OVER), in, csize, (uint32_t)s + 1);
+        next_issued = true;
+    };
+    auto refill = [&]() { need(q); w = pk_fetch8(stages, q); avail = 8; };
+
+    while (status == 0) {
+        // ---- token + literal length ----
+        if (q >= csize) { status = 1; break; }
+        if (avail == 0) refill();
+        const uint32_t token = (uint32_t)w & 0xFF; w >>= 8; avail--; q++;
+        uint32_t lit = token >> 4;
+        if (lit == 15) {
+            for (;;) {
+                if (q >= csize) { status = 1; break; }
+                if (avail == 0) refill();
+                const uint32_t s = (uint32_t)w & 0xFF; w >>= 8; avail--; q++;
+                lit += s;
+                if (s != 255) break;
+                if (lit > 0x7FFFFFFFu - 255u) { status = 1; break; }
+            }
+            if (status) break;
+        }
+        if (q > csize) { status = 1; break; }
+        const uint32_t in_left = csize - q, out_left = cap - op;
+        const uint32_t lit_src = q;
+        uint32_t mlen = 0, off = 0;
+        const bool is_last = (uint64_t)lit + 12 > out_left || (uint64_t)lit + 8 > in_left;
+        if (is_last) {
+            if (lit != in_left || lit > out_left) { status = 1; break; }
+        } else {
+            // ---- match header (>= 8 payload bytes remain after the literals) ----
+            if (lit) { q += lit; if (lit >= avail) avail = 0; else { w >>= 8 * lit; avail -= lit; } }
+            if (avail < 2) refill();
+            off = (uint32_t)w & 0xFFFF; w >>= 16; avail -= 2; q += 2;
+            if (off == 0) { status = 1; break; }
+            if (off > op + lit + (linked ? 65535u : 0u)) { status = 1; break; }     // exact history check for linked frames: copy kernel
+            mlen = token & 15;
+            if (mlen == 15) {
+                for (;;) {
+                    if (q >= csize) { status = 1; break; }
+                    if (avail == 0) refill();
+                    const uint32_t s = (uint32_t)w & 0xFF; w >>= 8; avail--; q++;
+                    mlen += s;
+                    if (q + 4 >= csize) { status = 1; break; }
+                    if (s != 255) break;
+                    if (mlen > 0x7FFFFFFFu - 255u) { status = 1; break; }
+                }
+                if (status) break;
+            }
+            mlen += 4;
+            if ((uint64_t)mlen + 5 > (uint64_t)(cap - (op + lit))) { status = 1; break; }
+        }
+        // ---- commit the descriptor into lane (nseq & 63) ----
+        if (nseq >= dcap) { status = 1; break; }
+        const uint32_t slot = nseq & 63;
+        const bool mine = lane == slot;                  // select, not branch: the loop stays scalar
+        d0 = mine ? (lit_src | ((off & 0xFFu) << 24)) : d0;
+        d1 = mine ? (lit | ((off >> 8) << 24)) : d1;
+        d2 = mine ? op : d2;
+        d3 = mine ? mlen : d3;
+        nseq++;
+        op += lit + mlen;
+        if (slot == 63) {                         // 64 gathered: one coalesced 1 KiB store, no lane predicate (keeps the loop scalar)
+            SeqDesc d; d.x = d0; d.y = d1; d.z = d2; d.w = d3; dout[nseq - 64 + lane] = d;
+        }
+        if (is_last) break;
+    }
+    if (status == 0 && (nseq & 63) && lane < (nseq & 63)) { SeqDesc d; d.x = d0; d.y = d1; d.z = d2; d.w = d3; dout[(nseq & ~63u) + lane] = d; }
+    if (lane == 0) { seq_count[blk] = status ? 0xFFFFFFFFu : nseq; out_size[blk] = op; }
+}
+
+// ------------------------------- kernel 2: copy --------------------------------------------------
+struct alignas(16) CkShared {
+    uint32_t lit_src[CK_NB], lit_len[CK_NB], dst[CK_NB], mlen[CK_NB], moff[CK_NB];     // moff bit31 = deferred
+    uint32_t n_def, bad;
+};
+
+// Replays the descriptors of one block with the whole workgroup.  `hist`: valid bytes in front of `out`.
+// Returns false when a descriptor violates a bound that only this kernel can check (linked-frame history).
+__device__ __forceinline__ bool wg_copy_block(CkShared& sh, const uint8_t* __restrict__ in, uint8_t* out, const SeqDesc* __restrict__ dsc, uint32_t nseq,
+                                              uint64_t hist, uint32_t room)
+{
+    const uint32_t tid = threadIdx.x, wave = uni(tid >> 6);
+    bool ok = true;
+    for (uint32_t b0 = 0; b0 < nseq; b0 += CK_NB) {
+        const uint32_t n = uni((nseq - b0 < (uint32_t)CK_NB) ? nseq - b0 : (uint32_t)CK_NB);
+        __syncthreads();                                                // previous batch is completely done with LDS
+        if (tid == 0) { sh.n_def = 0; sh.bad = 0; }
+        if (tid < n) {
+            const SeqDesc d = dsc[b0 + tid];
+            sh.lit_src[tid] = d.x & 0xFFFFFFu; sh.lit_len[tid] = d.y & 0xFFFFFFu; sh.dst[tid] = d.z; sh.mlen[tid] = d.w;
+            sh.moff[tid] = (d.x >> 24) | ((d.y >> 24) << 8);
+        }
+        __syncthreads();
+        // ---- dependency test (one lane per sequence) ----
+        if (tid < n) {
+            const uint32_t k = tid;
+            const uint32_t ml = sh.mlen[k];
+            const uint32_t ll = sh.lit_len[k], dd = sh.dst[k];
+            if ((uint64_t)dd + ll + ml > room) atomicOr(&sh.bad, 1u);
+            if (ml) {
+                const uint32_t dm = dd + ll;
+                const uint32_t off = sh.moff[k];
+                if ((uint64_t)off > (uint64_t)dm + hist) atomicOr(&sh.bad, 1u);
+                const int64_t s_start = (int64_t)dm - off;
+                const int64_t s_end = (off < ml) ? (int64_t)dm : s_start + ml;
+                uint32_t lo = 0, hi = k;                                // number of j < k with dm_j < s_end
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((int64_t)(sh.dst[mid] + sh.lit_len[mid]) < s_end) lo = mid + 1; else hi = mid;
+                }
+                if (lo > 0) {
+                    const uint32_t j = lo - 1;
+                    const int64_t dj_end = (int64_t)(sh.dst[j] + sh.lit_len[j]) + sh.mlen[j];
+                    if (dj_end > s_start) { sh.moff[k] = off | 0x80000000u; atomicAdd(&sh.n_def, 1u); }
+                }
+            }
+        }
+        __syncthreads();
+        if (uni(sh.bad)) { ok = false; break; }
+        // ---- literals: no dependencies; short runs one wave each, long runs sliced over the waves ----
+        for (uint32_t k = 0; k < n; k++) {
+            const uint32_t len = uni(sh.lit_len[k]);
+            if (len == 0) continue;
+            if (len <= 8192) {
+                if ((k & (CK_WAVES - 1)) == wave) wave_copy_disjoint(out + uni(sh.dst[k]), in + uni(sh.lit_src[k]), len);
+            } else {
+                const uint32_t per = (((len + CK_WAVES - 1) / CK_WAVES) + 15) & ~15u;
+                const uint32_t a = wave * per;
+                if (a < len) wave_copy_disjoint(out + uni(sh.dst[k]) + a, in + uni(sh.lit_src[k]) + a, (len - a < per) ? len - a : per);
+            }
+        }
+        __syncthreads();                                                // literals of this batch are in memory
+        // ---- safe matches, all waves ----
+        const uint32_t ndef = uni(sh.n_def);
+        for (uint32_t k = wave; k < n; k += CK_WAVES) {
+            const uint32_t ml = uni(sh.mlen[k]);
+            const uint32_t mo = uni(sh.moff[k]);
+            if (ml && !(mo >> 31)) wave_copy_match(out + uni(sh.dst[k]) + uni(sh.lit_len[k]), mo, ml);
+        }
+        if (ndef) {                                                     // deferred matches: stream order, one wave
+            __syncthreads();
+            if (wave == 0) {
+                for (uint32_t k = 0; k < n; k++) {
+                    const uint32_t mo = uni(sh.moff[k]);
+                    if (mo >> 31) wave_copy_match(out + uni(sh.dst[k]) + uni(sh.lit_len[k]), mo & 0xFFFFu, uni(sh.mlen[k]));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    return ok;
+}
+
+__global__ __launch_bounds__(64 * CK_WAVES) void k_copy_blocks(const uint8_t* __restrict__ frame, uint8_t* dst, uint64_t dst_cap,
+                                                               BlockOut* __restrict__ table, const ResultRec* __restrict__ res,
+                                                               uint32_t n_max, uint32_t linked, uint32_t block_size, uint64_t hist0,
+                                                               const SeqDesc* __restrict__ desc, const uint32_t* __restrict__ seq_count,
+                                                               const uint32_t* __restrict__ out_size)
+{
+    __shared__ CkShared sh;
+    if (res->status != ST_OK) return;
+    const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    const uint32_t tid = threadIdx.x;
+    if (linked && blockIdx.x != 0) return;
+    uint32_t b = linked ? 0u : blockIdx.x;
+    const uint32_t b_end = linked ? n : (b < n ? b + 1 : b);
+    uint64_t out = 0;
+    for (; b < b_end; b++) {
+        const BlockOut e = table[b];
+        const uint32_t csz = e.word & 0x7FFFFFFFu;
+        const uint64_t at = linked ? out : e.dst_off;
+        const uint32_t room = linked ? (uint32_t)((dst_cap - out < block_size) ? dst_cap - out : block_size) : e.dst_size;
+        int32_t got;
+        if (e.word >> 31) {                                              // stored block: all waves copy a slice
+            if (csz > room) got = -2;
+            else {
+                const uint32_t per = (((csz + CK_WAVES - 1) / CK_WAVES) + 15) & ~15u;
+                const uint32_t a = (tid >> 6) * per;
+                if (a < csz) wave_copy_disjoint(dst + at + a, frame + e.src_off + a, (csz - a < per) ? csz - a : per);
+                got = (int32_t)csz;
+            }
+        } else {
+            const uint32_t ns = seq_count[b];
+            if (ns == 0xFFFFFFFFu || out_size[b] > room) got = -1;
+            else {
+                const bool ok = wg_copy_block(sh, frame + e.src_off, dst + at, desc + (uint64_t)b * max_seq_per_block(block_size), ns,
+                                              linked ? out + hist0 : 0, room);
+                got = ok ? (int32_t)out_size[b] : -1;
+            }
+        }
+        if (tid == 0) { table[b].dst_off = at; table[b].dst_size = (uint32_t)got; }
+        if (got < 0) {
+            if (linked) for (uint32_t k = b + 1 + tid; k < n; k += 64 * CK_WAVES) table[k].dst_size = 0;
+            break;
+        }
+        out += (uint32_t)got;
+        __syncthreads();
+    }
+}
+
+}  // namespace lz4f

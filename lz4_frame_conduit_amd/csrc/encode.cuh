@@ -214,15 +214,6 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
 }
 
 // ------------------------------- pass S --------------------------------------------------------
-struct BlockOut {            // mirrors lz4f_mi355x_block
-    uint64_t src_off, dst_off;
-    uint32_t word, dst_size;
-};
-struct ResultRec {           // mirrors lz4f_mi355x_result
-    uint64_t size, consumed;
-    uint32_t status, n_blocks, first_bad_block, flags;
-};
-
 // one workgroup of 1024 threads: per-block sizes, then a chunked exclusive scan over the blocks
 __global__ __launch_bounds__(1024) void k_layout(EncGeom g, ChunkInfo* __restrict__ info, BlockOut* __restrict__ table,
                                                  uint32_t* __restrict__ blk_bytes /* n_blocks scratch */,

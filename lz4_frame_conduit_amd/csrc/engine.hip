@@ -116,10 +116,11 @@ lz4f_mi355x_engine::~lz4f_mi355x_engine()
 {
     (void)hipSetDevice(device);
     (void)hipStreamSynchronize((hipStream_t)stream);
+    desc.release(); seqcnt.release();
     info.release(); recs.release(); table.release(); blk_bytes.release(); res.release(); bad.release();
     d_in.release(); d_out.release();
     h_in.release(); h_out.release(); h_small.release();
-    for (int i = 0; i < 16; i++) if (ev[i]) (void)hipEventDestroy((hipEvent_t)ev[i]);
+    for (int i = 0; i < 20; i++) if (ev[i]) (void)hipEventDestroy((hipEvent_t)ev[i]);
     if (own_stream && stream) (void)hipStreamDestroy((hipStream_t)stream);
 }
 
@@ -220,7 +221,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         tick(4, true);
     }
     HIP_TRY(hipMemsetAsync(bad.p, 0xFF, 4, st));
-    for (int i = 4; i < 8; i++) ev_used[i] = false;
+    for (int i = 4; i < 10; i++) ev_used[i] = false;
     constexpr int W = 4;
     const uint32_t grid = j.linked ? 1u : (n_max + W - 1) / W;
     if (n_max) {
@@ -231,8 +232,25 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             tick(5, true);
         }
         tick(6, false);
-        hipLaunchKernelGGL((k_decode_blocks<W>), dim3(grid), dim3(64 * W), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl, (const ResultRec*)d_res,
-                           n_max, j.linked ? 1u : 0u, j.block_size, j.hist0);
+        // one workgroup (8 waves) per block when blocks are few and large, one wave per block otherwise
+        bool two = j.linked || j.block_size >= (256u << 10);
+        if (const char* dv = getenv("LZ4F_MI355X_DECODE")) two = (dv[0] == '2');
+        if (two) {
+            const size_t per_block = (size_t)j.block_size / 4 + 2;
+            if (desc.ensure((size_t)n_max * per_block * sizeof(SeqDesc)) || seqcnt.ensure((size_t)n_max * 8 + 64)) return make_err(LZ4F_ERROR_allocation_failed);
+            uint32_t* cnt = (uint32_t*)seqcnt.p; uint32_t* osz = cnt + n_max;
+            tick(8, false);
+            hipLaunchKernelGGL(k_parse_blocks, dim3((n_max + PK_WAVES - 1) / PK_WAVES), dim3(64 * PK_WAVES), 0, st, j.d_frame, (const BlockOut*)tbl,
+                               (const ResultRec*)d_res, n_max, j.block_size, j.linked ? 1u : 0u, (SeqDesc*)desc.p, cnt, osz);
+            tick(8, true);
+            tick(9, false);
+            hipLaunchKernelGGL(k_copy_blocks, dim3(j.linked ? 1u : n_max), dim3(64 * CK_WAVES), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
+                               (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, j.hist0, (const SeqDesc*)desc.p, (const uint32_t*)cnt,
+                               (const uint32_t*)osz);
+            tick(9, true);
+        } else
+            hipLaunchKernelGGL((k_decode_blocks<W>), dim3(grid), dim3(64 * W), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl, (const ResultRec*)d_res,
+                               n_max, j.linked ? 1u : 0u, j.block_size, j.hist0);
         tick(6, true);
     }
     tick(7, false);

@@ -53,11 +53,12 @@ struct lz4f_mi355x_engine {
     void* stream = nullptr;        // hipStream_t
     bool  own_stream = false;
     lz4f::DevBuf info, recs, table, blk_bytes, res, bad;   // workspace of the block kernels
+    lz4f::DevBuf desc, seqcnt;                             // two-kernel decode: sequence descriptors, per-block counts
     lz4f::DevBuf d_in, d_out;                              // staging for the host-pointer paths
     lz4f::PinBuf h_in, h_out, h_small;
     bool  timing = false;
-    void* ev[16] = {nullptr};      // hipEvent_t pairs (begin,end) per timing slot
-    bool  ev_used[8] = {false};
+    void* ev[20] = {nullptr};      // hipEvent_t pairs (begin,end) per timing slot
+    bool  ev_used[10] = {false};
     void  tick(int slot, bool end);
 
     // ---- device-pointer paths (asynchronous on `stream`) ----

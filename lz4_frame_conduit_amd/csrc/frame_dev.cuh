@@ -7,6 +7,7 @@
 #pragma once
 #include "common.cuh"
 #include "decode.cuh"
+#include "decode_2k.cuh"
 #include "encode.cuh"
 
 namespace lz4f {

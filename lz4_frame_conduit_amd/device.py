@@ -46,13 +46,13 @@ class Engine:
         except Exception:
             pass
 
-    TIMING_SLOTS = ("find_matches", "layout", "emit", "xxh32_write", "walk", "xxh32_verify", "decode", "finish")
+    TIMING_SLOTS = ("find_matches", "layout", "emit", "xxh32_write", "walk", "xxh32_verify", "decode", "finish", "decode_parse", "decode_copy")
 
     def set_timing(self, on: bool):
         _chk(self.L, self.L.lz4f_mi355x_engine_set_timing(self.h, 1 if on else 0))
 
     def get_timing(self) -> dict:
-        ms = (ctypes.c_float * 8)()
+        ms = (ctypes.c_float * 10)()
         _chk(self.L, self.L.lz4f_mi355x_engine_get_timing(self.h, ms))
         return dict(zip(self.TIMING_SLOTS, [float(x) for x in ms]))
 
