@@ -80,7 +80,7 @@ def main():
     import torch
     import torch.distributed as dist
 
-    from lz4_frame_conduit_amd import conduit
+    from lz4_frame_conduit_amd import conduit, shard
     from lz4_frame_conduit_amd.device import Engine, synth50_device
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -113,9 +113,7 @@ def main():
         eng.decompress_blocks_async(frame, frame.numel(), back, table, nb, prefs.frameInfo)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        shard.barrier_all(torch.device(dev))
 
     for _ in range(args.warmup):
         step()
@@ -135,10 +133,7 @@ def main():
                 kt.setdefault(k, []).append(v)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = shard.max_over_ranks(dt, dev)
     r2 = eng.result()
     ok = bool(r2.size == n and torch.equal(back, src))
 
