@@ -62,6 +62,25 @@ __device__ __forceinline__ void wave_copy_disjoint(uint8_t* __restrict__ dst, co
     }
 }
 
+// One-round (len <= 1024) disjoint copy split into its load and its store, so that a wave can keep several
+// copies in flight: issue the loads of 4 copies, then their stores (a lone load->store pair per wave leaves
+// only ~16 KiB in flight per CU, half of what HBM latency x bandwidth needs).
+struct Piece { b16_ua v; };
+__device__ __forceinline__ void piece_load(Piece& p, const uint8_t* __restrict__ src, uint32_t len)
+{
+    const uint32_t lane = lane_id(), nfull = len >> 4, tail = len & 15;
+    if (len < 16) { if (lane < len) p.v.a = src[lane]; }
+    else if (lane < nfull) p.v = *(const b16_ua*)(src + lane * 16);
+    else if (lane == nfull && tail) p.v = *(const b16_ua*)(src + len - 16);
+}
+__device__ __forceinline__ void piece_store(const Piece& p, uint8_t* __restrict__ dst, uint32_t len)
+{
+    const uint32_t lane = lane_id(), nfull = len >> 4, tail = len & 15;
+    if (len < 16) { if (lane < len) dst[lane] = (uint8_t)p.v.a; }
+    else if (lane < nfull) *(b16_ua*)(dst + lane * 16) = p.v;
+    else if (lane == nfull && tail) *(b16_ua*)(dst + len - 16) = p.v;
+}
+
 // LZ4 match copy: dst[i] = dst[i - offset] for i in [0,len), increasing i (forward overlap
 // semantics).  dst - offset .. dst is already written by THIS wave
 // (vector memory operations of one wave are performed in issue order), or by earlier kernels.

@@ -112,6 +112,24 @@ __global__ __launch_bounds__(64 * PK_WAVES) void k_parse_blocks(const uint8_t* _
         next_issued = true;
     };
     auto refill = [&]() { need(q); w = pk_fetch8(stages, q); avail = 8; };
+    // LZ4 length bytes (255, 255, ..., <255) decoded without a per-byte loop: the number of leading 0xFF bytes of
+    // the window is ctz(~w) / 8.  Returns the value added by the length bytes; q/w/avail advance past them.
+    auto len_bytes = [&]() -> uint32_t {
+        uint32_t add = 0;
+        for (;;) {
+            if (avail == 0) refill();
+            const uint64_t inv = ~w;
+            const uint32_t k = inv ? (uint32_t)(__builtin_ctzll(inv) >> 3) : 8u;      // leading 0xFF bytes in the window
+            if (k < avail) {                                                          // terminator is in the window
+                add += 255u * k + (uint32_t)((w >> (8 * k)) & 0xFF);
+                const uint32_t used = k + 1;
+                w = used < 8 ? (w >> (8 * used)) : 0; avail -= used; q += used;
+                return add;
+            }
+            add += 255u * avail; q += avail; avail = 0;                               // all 0xFF so far: keep going
+            if (add > 0x7FFF0000u || q >= csize) { status = 1; return add; }
+        }
+    };
 
     while (status == 0) {
         // ---- token + literal length ----
@@ -119,17 +137,7 @@ __global__ __launch_bounds__(64 * PK_WAVES) void k_parse_blocks(const uint8_t* _
         if (avail == 0) refill();
         const uint32_t token = (uint32_t)w & 0xFF; w >>= 8; avail--; q++;
         uint32_t lit = token >> 4;
-        if (lit == 15) {
-            for (;;) {
-                if (q >= csize) { status = 1; break; }
-                if (avail == 0) refill();
-                const uint32_t s = (uint32_t)w & 0xFF; w >>= 8; avail--; q++;
-                lit += s;
-                if (s != 255) break;
-                if (lit > 0x7FFFFFFFu - 255u) { status = 1; break; }
-            }
-            if (status) break;
-        }
+        if (lit == 15) { lit += len_bytes(); if (status) break; }
         if (q > csize) { status = 1; break; }
         const uint32_t in_left = csize - q, out_left = cap - op;
         const uint32_t lit_src = q;
@@ -146,16 +154,8 @@ __global__ __launch_bounds__(64 * PK_WAVES) void k_parse_blocks(const uint8_t* _
             if (off > op + lit + (linked ? 65535u : 0u)) { status = 1; break; }     // exact history check for linked frames: copy kernel
             mlen = token & 15;
             if (mlen == 15) {
-                for (;;) {
-                    if (q >= csize) { status = 1; break; }
-                    if (avail == 0) refill();
-                    const uint32_t s = (uint32_t)w & 0xFF; w >>= 8; avail--; q++;
-                    mlen += s;
-                    if (q + 4 >= csize) { status = 1; break; }
-                    if (s != 255) break;
-                    if (mlen > 0x7FFFFFFFu - 255u) { status = 1; break; }
-                }
-                if (status) break;
+                mlen += len_bytes(); if (status) break;
+                if (q + 4 >= csize) { status = 1; break; }                          // length bytes may not reach the last 5 payload bytes
             }
             mlen += 4;
             if ((uint64_t)mlen + 5 > (uint64_t)(cap - (op + lit))) { status = 1; break; }
@@ -180,81 +180,138 @@ __global__ __launch_bounds__(64 * PK_WAVES) void k_parse_blocks(const uint8_t* _
 }
 
 // ------------------------------- kernel 2: copy --------------------------------------------------
+constexpr uint32_t CK_MAX_LEVEL = 12;           // dependency chains deeper than this are replayed in stream order
+constexpr uint32_t CK_SERIAL = 255;
 struct alignas(16) CkShared {
-    uint32_t lit_src[CK_NB], lit_len[CK_NB], dst[CK_NB], mlen[CK_NB], moff[CK_NB];     // moff bit31 = deferred
-    uint32_t n_def, bad;
+    uint32_t lit_src[CK_NB], lit_len[CK_NB], dst[CK_NB], mlen[CK_NB], moff[CK_NB];
+    uint32_t dep[CK_NB];                        // jlo | jhi << 16: earlier matches of the batch whose destination overlaps my source
+    uint32_t level[CK_NB];                      // 0: no in-batch dependency; L: longest dependency chain; CK_SERIAL: replay in order
+    uint32_t bad, any_long, changed, max_level, n_serial, pad[3];
 };
 
 // Replays the descriptors of one block with the whole workgroup.  `hist`: valid bytes in front of `out`.
 // Returns false when a descriptor violates a bound that only this kernel can check (linked-frame history).
 __device__ __forceinline__ bool wg_copy_block(CkShared& sh, const uint8_t* __restrict__ in, uint8_t* out, const SeqDesc* __restrict__ dsc, uint32_t nseq,
-                                              uint64_t hist, uint32_t room)
+                                              uint64_t hist, uint32_t room, uint32_t dbg)
 {
     const uint32_t tid = threadIdx.x, wave = uni(tid >> 6);
     bool ok = true;
     for (uint32_t b0 = 0; b0 < nseq; b0 += CK_NB) {
         const uint32_t n = uni((nseq - b0 < (uint32_t)CK_NB) ? nseq - b0 : (uint32_t)CK_NB);
         __syncthreads();                                                // previous batch is completely done with LDS
-        if (tid == 0) { sh.n_def = 0; sh.bad = 0; }
+        if (tid == 0) { sh.bad = 0; sh.any_long = 0; sh.changed = 0; sh.max_level = 0; sh.n_serial = 0; }
         if (tid < n) {
             const SeqDesc d = dsc[b0 + tid];
             sh.lit_src[tid] = d.x & 0xFFFFFFu; sh.lit_len[tid] = d.y & 0xFFFFFFu; sh.dst[tid] = d.z; sh.mlen[tid] = d.w;
             sh.moff[tid] = (d.x >> 24) | ((d.y >> 24) << 8);
+            sh.level[tid] = 0;
         }
         __syncthreads();
-        // ---- dependency test (one lane per sequence) ----
-        if (tid < n) {
+        // ---- dependency test (one lane per sequence): which earlier matches of this batch write bytes my match reads?
+        // Match destinations D_j = [dm_j, dm_j + mlen_j) are disjoint and increasing in j, so the overlapping ones form a
+        // contiguous range [jlo, jhi] found by two binary searches.
+        bool has_dep = false; uint32_t jlo = 0, jhi = 0;
+        if (tid < n && !(dbg & 4)) {
             const uint32_t k = tid;
             const uint32_t ml = sh.mlen[k];
             const uint32_t ll = sh.lit_len[k], dd = sh.dst[k];
             if ((uint64_t)dd + ll + ml > room) atomicOr(&sh.bad, 1u);
+            if (ll > 65536) atomicOr(&sh.any_long, 1u);
             if (ml) {
                 const uint32_t dm = dd + ll;
                 const uint32_t off = sh.moff[k];
                 if ((uint64_t)off > (uint64_t)dm + hist) atomicOr(&sh.bad, 1u);
                 const int64_t s_start = (int64_t)dm - off;
                 const int64_t s_end = (off < ml) ? (int64_t)dm : s_start + ml;
-                uint32_t lo = 0, hi = k;                                // number of j < k with dm_j < s_end
+                uint32_t lo = 0, hi = k;                                // #(j < k with dm_j < s_end)
                 while (lo < hi) {
                     const uint32_t mid = (lo + hi) >> 1;
                     if ((int64_t)(sh.dst[mid] + sh.lit_len[mid]) < s_end) lo = mid + 1; else hi = mid;
                 }
-                if (lo > 0) {
-                    const uint32_t j = lo - 1;
-                    const int64_t dj_end = (int64_t)(sh.dst[j] + sh.lit_len[j]) + sh.mlen[j];
-                    if (dj_end > s_start) { sh.moff[k] = off | 0x80000000u; atomicAdd(&sh.n_def, 1u); }
+                const uint32_t cnt_hi = lo;
+                lo = 0; hi = k;                                         // #(j < k with dm_j + mlen_j <= s_start)
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((int64_t)(sh.dst[mid] + sh.lit_len[mid]) + sh.mlen[mid] <= s_start) lo = mid + 1; else hi = mid;
                 }
+                jlo = lo;
+                if (cnt_hi > jlo) { has_dep = true; jhi = cnt_hi - 1; sh.level[k] = 1; }
             }
         }
         __syncthreads();
         if (uni(sh.bad)) { ok = false; break; }
-        // ---- literals: no dependencies; short runs one wave each, long runs sliced over the waves ----
-        for (uint32_t k = 0; k < n; k++) {
-            const uint32_t len = uni(sh.lit_len[k]);
-            if (len == 0) continue;
-            if (len <= 8192) {
-                if ((k & (CK_WAVES - 1)) == wave) wave_copy_disjoint(out + uni(sh.dst[k]), in + uni(sh.lit_src[k]), len);
-            } else {
+        // ---- levels by relaxation: level[k] = 1 + max(level[jlo..jhi]); converges in (longest chain) rounds ----
+        for (uint32_t it = 0; it < CK_MAX_LEVEL + 1; it++) {
+            if (has_dep) {
+                uint32_t m = 0;
+                if (jhi - jlo >= 8) m = CK_SERIAL;                       // very wide source: do not bother, replay in order
+                else for (uint32_t j = jlo; j <= jhi; j++) { const uint32_t l = sh.mlen[j] ? sh.level[j] : 0; m = l > m ? l : m; }
+                uint32_t nl = m >= CK_MAX_LEVEL ? CK_SERIAL : m + 1;
+                if (nl != sh.level[tid]) { sh.level[tid] = nl; sh.changed = 1; }
+            }
+            __syncthreads();
+            const uint32_t ch = uni(sh.changed);
+            __syncthreads();
+            if (!ch) break;
+            if (tid == 0) sh.changed = 0;
+            __syncthreads();
+        }
+        if (has_dep) { const uint32_t l = sh.level[tid]; if (l == CK_SERIAL) atomicAdd(&sh.n_serial, 1u); else atomicMax(&sh.max_level, l); }
+        // ---- literals: no dependencies.  Each wave takes every 8th sequence, 4 at a time: 4 loads in flight, then 4 stores.
+        for (uint32_t i0 = wave; i0 < n && !(dbg & 1); i0 += 4 * CK_WAVES) {
+            uint32_t len[4]; const uint8_t* sp[4]; uint8_t* dp[4]; Piece pc[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t k = i0 + u * CK_WAVES;
+                const uint32_t kk = k < n ? k : 0;
+                len[u] = k < n ? uni(sh.lit_len[kk]) : 0;
+                sp[u] = in + uni(sh.lit_src[kk]); dp[u] = out + uni(sh.dst[kk]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (len[u] && len[u] <= 1024) piece_load(pc[u], sp[u], len[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (len[u] && len[u] <= 1024) piece_store(pc[u], dp[u], len[u]);
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (len[u] > 1024 && len[u] <= 65536) wave_copy_disjoint(dp[u], sp[u], len[u]);
+        }
+        if (uni(sh.any_long)) {                                         // very long runs: sliced over all waves
+            for (uint32_t k = 0; k < n; k++) {
+                const uint32_t len = uni(sh.lit_len[k]);
+                if (len <= 65536) continue;
                 const uint32_t per = (((len + CK_WAVES - 1) / CK_WAVES) + 15) & ~15u;
                 const uint32_t a = wave * per;
                 if (a < len) wave_copy_disjoint(out + uni(sh.dst[k]) + a, in + uni(sh.lit_src[k]) + a, (len - a < per) ? len - a : per);
             }
         }
         __syncthreads();                                                // literals of this batch are in memory
-        // ---- safe matches, all waves ----
-        const uint32_t ndef = uni(sh.n_def);
-        for (uint32_t k = wave; k < n; k += CK_WAVES) {
-            const uint32_t ml = uni(sh.mlen[k]);
-            const uint32_t mo = uni(sh.moff[k]);
-            if (ml && !(mo >> 31)) wave_copy_match(out + uni(sh.dst[k]) + uni(sh.lit_len[k]), mo, ml);
+        // ---- matches level by level: everything a level-L match reads was written by literals or by levels < L ----
+        const uint32_t max_level = uni(sh.max_level), n_serial = uni(sh.n_serial);
+        for (uint32_t L = 0; L <= max_level && !(dbg & 2); L++) {
+            if (L) __syncthreads();
+            for (uint32_t i0 = wave; i0 < n; i0 += 4 * CK_WAVES) {
+                uint32_t ml[4], mo[4]; uint8_t* dp[4]; Piece pc[4]; bool fast[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t k = i0 + u * CK_WAVES;
+                    const uint32_t kk = k < n ? k : 0;
+                    ml[u] = (k < n && uni(sh.level[kk]) == L) ? uni(sh.mlen[kk]) : 0;
+                    mo[u] = uni(sh.moff[kk]);
+                    dp[u] = out + uni(sh.dst[kk]) + uni(sh.lit_len[kk]);
+                    fast[u] = ml[u] && ml[u] <= 1024 && mo[u] >= ml[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (fast[u]) piece_load(pc[u], dp[u] - mo[u], ml[u]);
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (fast[u]) piece_store(pc[u], dp[u], ml[u]);
+#pragma unroll
+                for (int u = 0; u < 4; u++) if (ml[u] && !fast[u]) wave_copy_match(dp[u], mo[u], ml[u]);
+            }
         }
-        if (ndef) {                                                     // deferred matches: stream order, one wave
+        if (n_serial) {                                                 // chains deeper than CK_MAX_LEVEL: stream order, one wave
             __syncthreads();
             if (wave == 0) {
-                for (uint32_t k = 0; k < n; k++) {
-                    const uint32_t mo = uni(sh.moff[k]);
-                    if (mo >> 31) wave_copy_match(out + uni(sh.dst[k]) + uni(sh.lit_len[k]), mo & 0xFFFFu, uni(sh.mlen[k]));
-                }
+                for (uint32_t k = 0; k < n; k++)
+                    if (uni(sh.level[k]) == CK_SERIAL) wave_copy_match(out + uni(sh.dst[k]) + uni(sh.lit_len[k]), uni(sh.moff[k]), uni(sh.mlen[k]));
             }
         }
     }
@@ -266,7 +323,7 @@ __global__ __launch_bounds__(64 * CK_WAVES) void k_copy_blocks(const uint8_t* __
                                                                BlockOut* __restrict__ table, const ResultRec* __restrict__ res,
                                                                uint32_t n_max, uint32_t linked, uint32_t block_size, uint64_t hist0,
                                                                const SeqDesc* __restrict__ desc, const uint32_t* __restrict__ seq_count,
-                                                               const uint32_t* __restrict__ out_size)
+                                                               const uint32_t* __restrict__ out_size, uint32_t dbg)
 {
     __shared__ CkShared sh;
     if (res->status != ST_OK) return;
@@ -295,7 +352,7 @@ __global__ __launch_bounds__(64 * CK_WAVES) void k_copy_blocks(const uint8_t* __
             if (ns == 0xFFFFFFFFu || out_size[b] > room) got = -1;
             else {
                 const bool ok = wg_copy_block(sh, frame + e.src_off, dst + at, desc + (uint64_t)b * max_seq_per_block(block_size), ns,
-                                              linked ? out + hist0 : 0, room);
+                                              linked ? out + hist0 : 0, room, dbg);
                 got = ok ? (int32_t)out_size[b] : -1;
             }
         }

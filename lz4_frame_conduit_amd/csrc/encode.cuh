@@ -84,10 +84,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
                                                                     ChunkInfo* __restrict__ info, uint64_t* __restrict__ recs)
 {
     __shared__ uint16_t s_table[WAVES_PER_WG][HASH_SIZE];
+    __shared__ uint8_t s_tag[WAVES_PER_WG][HASH_SIZE];      // 8 more hash bits per entry: filters false candidates without touching memory
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t chunk = uni(blockIdx.x * WAVES_PER_WG + wave);
     if (chunk >= g.n_chunks) return;
     uint16_t* table = s_table[wave];
+    uint8_t* tags = s_tag[wave];
 
     const uint32_t blk = chunk / g.chunks_per_block, cib = chunk % g.chunks_per_block;
     const uint64_t bstart = g.first_off + (uint64_t)blk * g.block_size;
@@ -111,16 +113,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
     // 64 KiB of positions, and later inserts win: seed the whole window sparsely (every SEED_STRIDE-th position,
     // roughly the density the skip-accelerated search itself leaves behind), then the last SEED_DENSE bytes densely.
     for (uint32_t i = lane; i < HASH_SIZE / 2; i += WAVE) ((uint32_t*)table)[i] = 0;
+    for (uint32_t i = lane; i < HASH_SIZE / 4; i += WAVE) ((uint32_t*)tags)[i] = 0;
     if (back >= 4) {
         const uint32_t dense_from = back > g.seed_dense ? back - g.seed_dense : 0;
         const uint32_t ss = g.seed_stride;
-        for (uint32_t q = 0; q < dense_from; q += WAVE * ss) {
-            const uint32_t p = q + lane * ss;
-            if (p < dense_from) table[(ld32(base + p) * 2654435761u) >> (32 - HASH_LOG)] = (uint16_t)p;
+        for (uint32_t q = 0; q < dense_from; q += 4 * WAVE * ss) {                  // 4 loads in flight per wave
+            uint32_t pp[4], vv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { pp[u] = q + (u * WAVE + lane) * ss; vv[u] = ld32(base + (pp[u] < dense_from ? pp[u] : 0u)); }
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (pp[u] < dense_from) { const uint32_t hv = vv[u] * 2654435761u; table[hv >> (32 - HASH_LOG)] = (uint16_t)pp[u]; tags[hv >> (32 - HASH_LOG)] = (uint8_t)(hv >> (24 - HASH_LOG)); }
         }
         for (uint32_t q = dense_from; q + 4 <= back; q += WAVE) {
             const uint32_t p = q + lane;
-            if (p + 4 <= back) table[(ld32(base + p) * 2654435761u) >> (32 - HASH_LOG)] = (uint16_t)p;
+            if (p + 4 <= back) { const uint32_t hv = ld32(base + p) * 2654435761u; table[hv >> (32 - HASH_LOG)] = (uint16_t)p; tags[hv >> (32 - HASH_LOG)] = (uint8_t)(hv >> (24 - HASH_LOG)); }
         }
     }
 
@@ -137,77 +143,158 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
         searchable = last_start >= cs;
     }
     if (searchable) {
+        // The search is latency-bound (a stream load, a table probe and a candidate gather per step), so two probe
+        // steps are kept in flight: step B = "the step after A if A finds nothing" is probed and inserted
+        // speculatively while A's candidate gather is still outstanding, and the stream loads run one more step
+        // ahead.  When A hits, B's table inserts (and A's beyond the hit) are rolled back from the values they
+        // overwrote, so the table evolves exactly as in the one-step-at-a-time formulation.
+        const uint32_t hmul = 2654435761u;
+        auto stream = [&](uint32_t ipx, uint32_t stepx) -> uint32_t {           // my 4 bytes of the step at (ipx, stepx)
+            const uint32_t px = ipx + lane * stepx;
+            return ld32(base + (px <= last_start ? px : last_start));       // unconditional load (clamped): no branch, no early wait
+        };
         uint32_t ip = cs, step = 1;
+        // stream queue: my 4 bytes for the next six steps along the all-miss path (A, B and two more iterations),
+        // so that the sequential input is always at least two iterations (~2 us) ahead of the probes
+        uint32_t s0, s1, s2, s3, s4, s5, ipN, stepN;
+        auto fill_queue = [&]() {
+            uint32_t i_ = ip, st_ = step;
+            s0 = stream(i_, st_); i_ += WAVE * st_; st_++;
+            s1 = stream(i_, st_); i_ += WAVE * st_; st_++;
+            s2 = stream(i_, st_); i_ += WAVE * st_; st_++;
+            s3 = stream(i_, st_); i_ += WAVE * st_; st_++;
+            s4 = stream(i_, st_); i_ += WAVE * st_; st_++;
+            s5 = stream(i_, st_); i_ += WAVE * st_; st_++;
+            ipN = i_; stepN = st_;
+        };
+        fill_queue();
         while (ip <= last_start) {
-            const uint32_t p = ip + lane * step;
-            const bool act = p <= last_start;
-            uint32_t seq = 0, e = 0, h = 0;
-            if (act) {
-                seq = ld32(base + p);
-                h = (seq * 2654435761u) >> (32 - HASH_LOG);
-                e = table[h];
-            }
-            const uint32_t d = (p - e) & 0xFFFFu;
-            const bool ok = act && d != 0 && d <= p;
-            const uint32_t cand = p - d;
-            uint32_t cseq = ~seq;
-            if (ok) cseq = ld32(base + cand);
-            const uint64_t hits = __ballot(ok && cseq == seq);
-            // insert only the positions the greedy parse really visits (up to and including the first hit):
-            // later lanes will be probed again from the end of the match and must not find themselves
-            const uint32_t L64 = hits ? (uint32_t)__builtin_ctzll(hits) : WAVE;
-            if (act && lane <= L64) table[h] = (uint16_t)p;
+            const uint32_t seqA = s0;
+            // ---- probe A ----
+            const uint32_t pA = ip + lane * step;
+            const bool actA = pA <= last_start;
+            const uint32_t hvA = seqA * hmul, hA = hvA >> (32 - HASH_LOG), tgA = (hvA >> (24 - HASH_LOG)) & 0xFFu;
+            uint32_t eA = 0, tA = 0x100;
+            if (actA) { eA = table[hA]; tA = tags[hA]; table[hA] = (uint16_t)pA; tags[hA] = (uint8_t)tgA; }
+            const uint32_t dA = (pA - eA) & 0xFFFFu;
+            const bool okA = actA && tA == tgA && dA != 0 && dA <= pA;            // same 20 hash bits: worth a look at the bytes
+            const uint32_t candA = pA - dA;
+            // ---- speculative probe B (next step if A misses) + stream prefetch for the step after B ----
+            const uint32_t ipB = ip + WAVE * step, stepB = step + 1;
+            const uint32_t seqB = s1;
+            const uint32_t pB = ipB + lane * stepB;
+            const bool actB = pB <= last_start;
+            const uint32_t hvB = seqB * hmul, hB = hvB >> (32 - HASH_LOG), tgB = (hvB >> (24 - HASH_LOG)) & 0xFFu;
+            uint32_t eB = 0, tB = 0x100;
+            if (actB) { eB = table[hB]; tB = tags[hB]; table[hB] = (uint16_t)pB; tags[hB] = (uint8_t)tgB; }
+            const uint32_t dB = (pB - eB) & 0xFFFFu;
+            const bool okB = actB && tB == tgB && dB != 0 && dB <= pB;
+            const uint32_t candB = pB - dB;
+            const uint32_t ipC = ipB + WAVE * stepB, stepC = stepB + 1;
+            // candidate bytes are fetched only when some lane passed the tag filter (wave-uniform branches: in literal
+            // regions almost every step skips the gather altogether)
+            uint32_t cseqA = ~seqA, cseqB = ~seqB;
+            const uint64_t candsA = __ballot(okA), candsB = __ballot(okB);
+            if (candsA) cseqA = ld32(base + (okA ? candA : 0u));
+            if (candsB) cseqB = ld32(base + (okB ? candB : 0u));
+            // ---- resolve A, then B ----
+            uint64_t hits = __ballot(okA && cseqA == seqA);
+            uint32_t p_hit = pA, cand_hit = candA;
+            bool hitB = false;
             if (hits == 0) {
-                ip += WAVE * step;
-                step += 1;
-                continue;
+                hits = __ballot(okB && cseqB == seqB);
+                if (hits == 0) {                                                    // both missed: advance two steps, top up the queue
+                    ip = ipC; step = stepC;
+                    s0 = s2; s1 = s3; s2 = s4; s3 = s5;
+                    s4 = stream(ipN, stepN); ipN += WAVE * stepN; stepN++;
+                    s5 = stream(ipN, stepN); ipN += WAVE * stepN; stepN++;
+                    continue;
+                }
+                hitB = true; p_hit = pB; cand_hit = candB;
             }
             const uint32_t L = (uint32_t)__builtin_ctzll(hits);
-            uint32_t mp = __builtin_amdgcn_readlane(p, L);
-            uint32_t mc = __builtin_amdgcn_readlane(cand, L);
-            // backward extension over pending literals
-            {
-                uint32_t room = mp - anchor; if (mc < room) room = mc;
-                while (room) {
-                    const uint32_t k = lane + 1;
-                    const bool in = k <= room;
-                    const bool eq = in && base[mp - k] == base[mc - k];
-                    const uint64_t ne = __ballot(!eq);
-                    const uint32_t nb = ne ? (uint32_t)__builtin_ctzll(ne) : WAVE;
-                    mp -= nb; mc -= nb; room -= nb;
-                    if (nb < WAVE) break;
-                }
+            // roll back the inserts the greedy parse does not make: lanes beyond the hit (and all of B when A hit)
+            if (!hitB) {
+                if (actB) { table[hB] = (uint16_t)eB; tags[hB] = (uint8_t)tB; }
+                if (actA && lane > L) { table[hA] = (uint16_t)eA; tags[hA] = (uint8_t)tA; }
+            } else {
+                if (actB && lane > L) { table[hB] = (uint16_t)eB; tags[hB] = (uint8_t)tB; }
             }
-            // forward extension, 8 B per lane, stopping at end_lim
+            uint32_t mp = __builtin_amdgcn_readlane(p_hit, L);
+            uint32_t mc = __builtin_amdgcn_readlane(cand_hit, L);
+            // backward extension over pending literals and forward extension (8 B per lane per round, two rounds): both
+            // start from the probe position, so all their loads are issued together and cost one memory round trip
+            const uint32_t dist = mp - mc;
+            const uint32_t fwd0 = mp + MINMATCH;
+            uint32_t room = mp - anchor; if (mc < room) room = mc;
+            const uint32_t kb = lane + 1;
+            uint8_t bb0 = 0, bb1 = 1;
+            if (kb <= room) { bb0 = base[mp - kb]; bb1 = base[mc - kb]; }
             uint32_t mlen = MINMATCH;
-            for (;;) {
-                const uint32_t a = mp + mlen + lane * 8;
-                uint32_t good = 0;                 // equal bytes in my 8-byte window (clipped at end_lim)
-                if (a < end_lim) {
-                    const uint64_t x = ld64_guard(base + a, rd_end) ^ ld64_guard(base + (a - (mp - mc)), rd_end);
-                    good = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8;
-                    const uint32_t room = end_lim - a;
-                    if (good > room) good = room;
+            {
+                const uint32_t a0 = fwd0 + lane * 8, a1 = a0 + WAVE * 8;
+                uint64_t x0 = 0, x1 = 0;
+                if (a0 < end_lim) x0 = ld64_guard(base + a0, rd_end) ^ ld64_guard(base + (a0 - dist), rd_end);
+                if (a1 < end_lim) x1 = ld64_guard(base + a1, rd_end) ^ ld64_guard(base + (a1 - dist), rd_end);
+                // backward
+                const uint64_t ne = __ballot(!(kb <= room && bb0 == bb1));
+                uint32_t nb = ne ? (uint32_t)__builtin_ctzll(ne) : WAVE;
+                if (nb == WAVE && room > WAVE) {                                   // rare: more than 64 bytes backwards
+                    uint32_t r2 = room - WAVE, m2 = mp - WAVE, c2 = mc - WAVE;
+                    while (r2) {
+                        const bool in = kb <= r2;
+                        const bool eq = in && base[m2 - kb] == base[c2 - kb];
+                        const uint64_t ne2 = __ballot(!eq);
+                        const uint32_t n2 = ne2 ? (uint32_t)__builtin_ctzll(ne2) : WAVE;
+                        nb += n2; m2 -= n2; c2 -= n2; r2 -= n2;
+                        if (n2 < WAVE) break;
+                    }
                 }
-                const uint64_t stop = __ballot(good < 8);
-                if (stop == 0) { mlen += WAVE * 8; continue; }
-                const uint32_t f = (uint32_t)__builtin_ctzll(stop);
-                mlen += f * 8 + __builtin_amdgcn_readlane(good, f);
-                break;
+                mp -= nb; mc -= nb; mlen += nb;
+                // forward: first two rounds from the loads above
+                uint32_t g0 = 0, g1 = 0;
+                if (a0 < end_lim) { g0 = x0 ? (uint32_t)(__builtin_ctzll(x0) >> 3) : 8; const uint32_t r = end_lim - a0; if (g0 > r) g0 = r; }
+                if (a1 < end_lim) { g1 = x1 ? (uint32_t)(__builtin_ctzll(x1) >> 3) : 8; const uint32_t r = end_lim - a1; if (g1 > r) g1 = r; }
+                const uint64_t stop0 = __ballot(g0 < 8);
+                bool more = false;
+                if (stop0) { const uint32_t f = (uint32_t)__builtin_ctzll(stop0); mlen += f * 8 + __builtin_amdgcn_readlane(g0, f); }
+                else {
+                    mlen += WAVE * 8;
+                    const uint64_t stop1 = __ballot(g1 < 8);
+                    if (stop1) { const uint32_t f = (uint32_t)__builtin_ctzll(stop1); mlen += f * 8 + __builtin_amdgcn_readlane(g1, f); }
+                    else { mlen += WAVE * 8; more = true; }
+                }
+                while (more) {                                                      // long matches: keep going, two rounds per trip
+                    const uint32_t b0 = mp + mlen + lane * 8, b1 = b0 + WAVE * 8;
+                    uint64_t y0 = 0, y1 = 0;
+                    if (b0 < end_lim) y0 = ld64_guard(base + b0, rd_end) ^ ld64_guard(base + (b0 - dist), rd_end);
+                    if (b1 < end_lim) y1 = ld64_guard(base + b1, rd_end) ^ ld64_guard(base + (b1 - dist), rd_end);
+                    uint32_t h0 = 0, h1 = 0;
+                    if (b0 < end_lim) { h0 = y0 ? (uint32_t)(__builtin_ctzll(y0) >> 3) : 8; const uint32_t r = end_lim - b0; if (h0 > r) h0 = r; }
+                    if (b1 < end_lim) { h1 = y1 ? (uint32_t)(__builtin_ctzll(y1) >> 3) : 8; const uint32_t r = end_lim - b1; if (h1 > r) h1 = r; }
+                    const uint64_t s0 = __ballot(h0 < 8);
+                    if (s0) { const uint32_t f = (uint32_t)__builtin_ctzll(s0); mlen += f * 8 + __builtin_amdgcn_readlane(h0, f); break; }
+                    mlen += WAVE * 8;
+                    const uint64_t s1 = __ballot(h1 < 8);
+                    if (s1) { const uint32_t f = (uint32_t)__builtin_ctzll(s1); mlen += f * 8 + __builtin_amdgcn_readlane(h1, f); break; }
+                    mlen += WAVE * 8;
+                }
             }
-            // append the sequence record
+            // append the sequence record (every lane stores the same 8 bytes: no lane-predicated branch in this loop)
             const uint32_t lit = mp - anchor;
-            if (lane == 0) rec[nrec] = pack_rec(lit, mlen, mp - mc);
+            rec[nrec] = pack_rec(lit, mlen, dist);
             if (nrec == 0) first_lit = lit;
             body += seq_size(lit, mlen);
             nrec++;
             anchor = ip = mp + mlen;
             step = 1;
-            if (lane == 0 && ip >= 2 + cs && ip + 2 <= ce) {          // like the CPU encoder: also index ip-2
-                const uint32_t q = ip - 2;
-                table[(ld32(base + q) * 2654435761u) >> (32 - HASH_LOG)] = (uint16_t)q;
-            }
-            if (nrec >= g.max_rec_per_chunk) break;          // cannot happen with ceil(chunk/4) slots; belt and braces
+            if (nrec >= g.max_rec_per_chunk) break;          // cannot happen with chunk/4+1 slots; belt and braces
+            // like the CPU encoder, also index ip-2; its bytes are requested together with the refilled stream queue
+            const bool ins2 = ip >= 2 + cs && ip + 2 <= ce;
+            const uint32_t q2 = ins2 ? ip - 2 : cs;
+            const uint32_t v2 = ld32(base + q2);
+            fill_queue();
+            if (ins2) { const uint32_t hv = v2 * hmul; table[hv >> (32 - HASH_LOG)] = (uint16_t)q2; tags[hv >> (32 - HASH_LOG)] = (uint8_t)(hv >> (24 - HASH_LOG)); }
         }
     }
     if (lane == 0) { ci->nrec = nrec; ci->first_lit = first_lit; ci->tail_lit = ce - anchor; ci->body_size = body; }

@@ -246,7 +246,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             tick(9, false);
             hipLaunchKernelGGL(k_copy_blocks, dim3(j.linked ? 1u : n_max), dim3(64 * CK_WAVES), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
                                (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, j.hist0, (const SeqDesc*)desc.p, (const uint32_t*)cnt,
-                               (const uint32_t*)osz);
+                               (const uint32_t*)osz, getenv("LZ4F_MI355X_DBG") ? (uint32_t)atoi(getenv("LZ4F_MI355X_DBG")) : 0u);
             tick(9, true);
         } else
             hipLaunchKernelGGL((k_decode_blocks<W>), dim3(grid), dim3(64 * W), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl, (const ResultRec*)d_res,
