@@ -65,20 +65,53 @@ __device__ __forceinline__ void wave_copy_disjoint(uint8_t* __restrict__ dst, co
 // One-round (len <= 1024) disjoint copy split into its load and its store, so that a wave can keep several
 // copies in flight: issue the loads of 4 copies, then their stores (a lone load->store pair per wave leaves
 // only ~16 KiB in flight per CU, half of what HBM latency x bandwidth needs).
-struct Piece { b16_ua v; };
+struct Piece { uint32_t a, b, c, d; };          // plain registers (a packed/unaligned struct here is kept in scratch by hipcc)
 __device__ __forceinline__ void piece_load(Piece& p, const uint8_t* __restrict__ src, uint32_t len)
 {
     const uint32_t lane = lane_id(), nfull = len >> 4, tail = len & 15;
-    if (len < 16) { if (lane < len) p.v.a = src[lane]; }
-    else if (lane < nfull) p.v = *(const b16_ua*)(src + lane * 16);
-    else if (lane == nfull && tail) p.v = *(const b16_ua*)(src + len - 16);
+    p.a = p.b = p.c = p.d = 0;
+    if (len < 16) { if (lane < len) p.a = src[lane]; }
+    else {
+        const bool body = lane < nfull, last = lane == nfull && tail;
+        if (body || last) {
+            const b16_ua t = *(const b16_ua*)(src + (body ? lane * 16 : len - 16));
+            p.a = t.a; p.b = t.b; p.c = t.c; p.d = t.d;
+        }
+    }
 }
 __device__ __forceinline__ void piece_store(const Piece& p, uint8_t* __restrict__ dst, uint32_t len)
 {
     const uint32_t lane = lane_id(), nfull = len >> 4, tail = len & 15;
-    if (len < 16) { if (lane < len) dst[lane] = (uint8_t)p.v.a; }
-    else if (lane < nfull) *(b16_ua*)(dst + lane * 16) = p.v;
-    else if (lane == nfull && tail) *(b16_ua*)(dst + len - 16) = p.v;
+    if (len < 16) { if (lane < len) dst[lane] = (uint8_t)p.a; }
+    else {
+        const bool body = lane < nfull, last = lane == nfull && tail;
+        if (body || last) *(b16_ua*)(dst + (body ? lane * 16 : len - 16)) = b16_ua{p.a, p.b, p.c, p.d};
+    }
+}
+
+// ---- copy pipeline primitives ------------------------------------------------------------------------------------------
+// A copy job is one round (16..1024 bytes) of a non-overlapping copy.  job_load is UNCONDITIONAL: every lane loads
+// 16 bytes (lanes without a piece read `safe`), so the load is never behind a branch and hipcc can count it exactly
+// (loads behind any branch make it fall back to s_waitcnt vmcnt(0), which serialises load->store->load).  Callers
+// ping-pong two register sets (no register moves between stages) so that the loads of the next jobs are in flight
+// while the current ones are stored.
+struct v4u_ua { uint32_t a, b, c, d; } __attribute__((packed, aligned(1)));
+struct CopyJob { const uint8_t* s; uint8_t* d; uint32_t n; };          // n in [16, 1024], or 0 = no job (wave-uniform)
+__device__ __forceinline__ void job_load(Piece& p, const CopyJob& j, const uint8_t* safe)
+{
+    const uint32_t lane = lane_id(), nfull = j.n >> 4, tail = j.n & 15;
+    const uint8_t* a = safe;
+    if (lane < nfull) a = j.s + lane * 16; else if (lane == nfull && tail) a = j.s + j.n - 16;
+    const v4u_ua t = *(const v4u_ua*)a;
+    p.a = t.a; p.b = t.b; p.c = t.c; p.d = t.d;
+}
+__device__ __forceinline__ void job_store(const CopyJob& j, const Piece& p)
+{
+    const uint32_t lane = lane_id(), nfull = j.n >> 4, tail = j.n & 15;
+    if (lane < nfull || (lane == nfull && tail)) {
+        uint8_t* a = (lane < nfull) ? j.d + lane * 16 : j.d + j.n - 16;
+        *(v4u_ua*)a = v4u_ua{p.a, p.b, p.c, p.d};
+    }
 }
 
 // LZ4 match copy: dst[i] = dst[i - offset] for i in [0,len), increasing i (forward overlap

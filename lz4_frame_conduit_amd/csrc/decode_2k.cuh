@@ -52,18 +52,24 @@ __device__ __forceinline__ void pk_stage_issue(uint8_t* slot, const uint8_t* __r
     if (lane < span - tail0) slot[tail0 + lane] = in[base + tail0 + lane];
 }
 
-// 8 payload bytes at position q from the stage slots (all operands wave-uniform)
+// 8 payload bytes at position q from the stage slots (all operands wave-uniform).
+// The three dword reads are inline asm on purpose: with ordinary LDS loads hipcc inserts `s_waitcnt vmcnt(0)` in front
+// of every read (a direct-to-LDS load may be pending, and it cannot know that it targets the OTHER slot), which would
+// serialise the parser behind its own prefetch.  Ordering is kept by hand: k_parse_blocks waits vmcnt(0) exactly when
+// it switches to a freshly loaded stage.
 __device__ __forceinline__ uint64_t pk_fetch8(const uint8_t* stages /* [2][STAGE+OVER] */, uint32_t q)
 {
     const uint32_t s = q / PK_STAGE;
     const uint32_t o = q - s * PK_STAGE;
-    const uint32_t* w = (const uint32_t*)(stages + (s & 1) * (PK_STAGE + PK_OVER));
-    const uint32_t i = o >> 2;
-    const uint32_t w0 = w[i], w1 = w[i + 1], w2 = w[i + 2];
+    const uint32_t addr = (uint32_t)(uintptr_t)(lptr_t)(stages + (s & 1) * (PK_STAGE + PK_OVER)) + (o & ~3u);
+    uint64_t w01; uint32_t w2;
+    asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(w01), "=&v"(w2) : "v"(addr) : "memory");
+    const uint64_t lo = uni64(w01);
+    const uint32_t hi = uni(w2);
     const uint32_t shv = (o & 3u) * 8;
-    uint64_t v = (((uint64_t)w1 << 32) | w0) >> shv;
-    if (shv) v |= (uint64_t)w2 << (64 - shv);
-    return uni64(v);
+    // funnel shift of the 96-bit value {hi, lo} by shv in {0, 8, 16, 24}
+    return (lo >> shv) | (((uint64_t)hi << 32) << (32 - shv));
 }
 
 // ------------------------------- kernel 1: parse -------------------------------------------------

@@ -1,0 +1,376 @@
+// decode_fused.cuh -- fused LZ4 block decode for large blocks: one WORKGROUP (8 waves) per frame block,
+// parse and copy overlapped.
+//
+// The sequence parse of a block is one serial dependent chain (~0.6 us per sequence on one wave); the copies are
+// where the bytes are.  Running them back to back (decode_2k.cuh) costs parse + copy; here they overlap, so a block
+// costs max(parse, copy) ~ parse:
+//   wave 0        PARSER.  Wave-uniform (SALU) state machine.  The payload streams through two 8 KiB LDS stages
+//                 filled by direct-to-LDS loads (global_load_lds_dwordx4) one stage ahead, one 8-byte LDS read per
+//                 sequence, length bytes decoded with ctz(~window).  64 descriptors are gathered in VGPR lanes and
+//                 written as one slot of an LDS ring; `produced` is bumped.
+//   waves 1..7    COPIERS.  Wave c takes ring slots c-1, c+6, ... : (1) literals of the slot, HBM -> HBM, 16 B/lane,
+//                 4 copies in flight; (2) waits until the matches of the previous slot are complete (`match_done`),
+//                 then replays its 64 matches in stream order, again up to 4 in flight when their sources cannot
+//                 touch each other's destinations; (3) s_waitcnt vmcnt(0), bumps `match_done`.
+// Waves of a workgroup are co-resident by construction, so the hand-offs are plain LDS words polled with s_sleep --
+// no workgroup barrier inside the loop, hence the parser never waits for a copier except when the ring is full.
+// Literal copies run ahead freely; match phases form a chain slot -> slot, which for 64-sequence slots is well
+// below the parse time.  LDS: 8 KiB ring + 16.1 KiB stages ~ 24.3 KiB per workgroup: 4 workgroups (32 waves) per CU.
+#pragma once
+#include "common.cuh"
+#include "decode.cuh"
+#include "decode_2k.cuh"
+
+namespace lz4f {
+
+constexpr int      FZ_WAVES = 8;
+constexpr uint32_t FZ_STAGE = 8192;
+constexpr uint32_t FZ_OVER = 64;
+constexpr uint32_t FZ_RING = 8;                 // slots of 64 descriptors
+
+struct alignas(16) FzShared {
+    uint4    ring[FZ_RING][64];
+    uint8_t  stage[2][FZ_STAGE + FZ_OVER];
+    uint32_t produced;                          // slots the parser has published
+    uint32_t total_slots;                       // valid once `finished` is set
+    uint32_t last_count;                        // descriptors in the last slot
+    uint32_t finished;                          // parser is done (ok or not)
+    uint32_t match_done;                        // slots whose matches are complete (in slot order)
+    int32_t  status;                            // < 0: malformed block
+    uint32_t out_size;
+    uint32_t pad;
+};
+static_assert(sizeof(FzShared) <= 40960, "4 workgroups per CU");
+
+__device__ __forceinline__ uint32_t lds_peek(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+__device__ __forceinline__ void lds_poke(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
+
+__device__ __forceinline__ void fz_stage_issue(uint8_t* slot, const uint8_t* __restrict__ in, uint32_t csize, uint32_t s)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t base = s * FZ_STAGE;
+    if (base >= csize) return;
+    const uint32_t end = (base + FZ_STAGE + FZ_OVER < csize) ? base + FZ_STAGE + FZ_OVER : csize;
+    const uint32_t span = end - base;
+    for (uint32_t piece = 0; piece < span; piece += 1024) {
+        const uint32_t o = piece + lane * 16;
+        if (o + 16 <= span) __builtin_amdgcn_global_load_lds((gptr_t)(in + base + o), (lptr_t)(slot + piece), 16, 0, 0);
+    }
+    const uint32_t tail0 = span & ~15u;
+    if (lane < span - tail0) slot[tail0 + lane] = in[base + tail0 + lane];
+}
+
+__device__ __forceinline__ uint64_t fz_fetch8(const uint8_t* stages, uint32_t q)
+{
+    const uint32_t s = q / FZ_STAGE;
+    const uint32_t o = q - s * FZ_STAGE;
+    const uint32_t addr = (uint32_t)(uintptr_t)(lptr_t)(stages + (s & 1) * (FZ_STAGE + FZ_OVER)) + (o & ~3u);
+    uint64_t w01; uint32_t w2;
+    // inline asm: see pk_fetch8 (decode_2k.cuh) -- keeps hipcc from waiting on the pending stage prefetch
+    asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(w01), "=&v"(w2) : "v"(addr) : "memory");
+    const uint64_t lo = uni64(w01);
+    const uint32_t hi = uni(w2);
+    const uint32_t shv = (o & 3u) * 8;
+    return (lo >> shv) | (((uint64_t)hi << 32) << (32 - shv));
+}
+
+// ---------------- parser wave ----------------
+__device__ __forceinline__ void fz_parser(FzShared& sh, const uint8_t* __restrict__ in, uint32_t csize, uint32_t cap, uint64_t hist,
+                                          unsigned long long* prof)
+{
+    const unsigned long long t_begin = clock64(); unsigned long long t_ring = 0;
+    const uint32_t lane = lane_id();
+    uint8_t* stages = &sh.stage[0][0];
+    uint32_t nseq = 0, status = 0;
+    uint32_t q = 0, op = 0;
+    uint64_t w = 0; uint32_t avail = 0;
+    int32_t  cur = -1;
+    uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+
+    if (csize == 0) status = 1;
+    else fz_stage_issue(stages, in, csize, 0);
+    auto need = [&](uint32_t qq) {
+        const int32_t s = (int32_t)(qq / FZ_STAGE);
+        if (s == cur) return;
+        if (s != cur + 1) {                                                      // a jump over a long literal run: load it now
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            fz_stage_issue(stages + (uint32_t)(s & 1) * (FZ_STAGE + FZ_OVER), in, csize, (uint32_t)s);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cur = s;
+        fz_stage_issue(stages + (uint32_t)((s + 1) & 1) * (FZ_STAGE + FZ_OVER), in, csize, (uint32_t)s + 1);
+    };
+    auto refill = [&]() { need(q); w = fz_fetch8(stages, q); avail = 8; };
+    auto len_bytes = [&]() -> uint32_t {
+        uint32_t add = 0;
+        for (;;) {
+            if (avail == 0) refill();
+            const uint64_t inv = ~w;
+            const uint32_t k = inv ? (uint32_t)(__builtin_ctzll(inv) >> 3) : 8u;
+            if (k < avail) {
+                add += 255u * k + (uint32_t)((w >> (8 * k)) & 0xFF);
+                const uint32_t used = k + 1;
+                w = used < 8 ? (w >> (8 * used)) : 0; avail -= used; q += used;
+                return add;
+            }
+            add += 255u * avail; q += avail; avail = 0;
+            if (add > 0x7FFF0000u || q >= csize) { status = 1; return add; }
+        }
+    };
+    // publish the gathered descriptors as ring slot number `slot_idx`
+    auto publish = [&](uint32_t slot_idx) {
+        const unsigned long long tr = clock64();
+        while (slot_idx >= lds_peek(&sh.match_done) + FZ_RING) __builtin_amdgcn_s_sleep(8);    // ring full: wait for the oldest slot
+        t_ring += clock64() - tr;
+        sh.ring[slot_idx % FZ_RING][lane] = uint4{d0, d1, d2, d3};
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_poke(&sh.produced, slot_idx + 1);
+    };
+
+    while (status == 0) {
+        if (q >= csize) { status = 1; break; }
+        if (avail == 0) refill();
+        const uint32_t token = (uint32_t)w & 0xFF; w >>= 8; avail--; q++;
+        uint32_t lit = token >> 4;
+        if (lit == 15) { lit += len_bytes(); if (status) break; }
+        if (q > csize) { status = 1; break; }
+        const uint32_t in_left = csize - q, out_left = cap - op;
+        const uint32_t lit_src = q;
+        uint32_t mlen = 0, off = 0;
+        const bool is_last = (uint64_t)lit + 12 > out_left || (uint64_t)lit + 8 > in_left;
+        if (is_last) {
+            if (lit != in_left || lit > out_left) { status = 1; break; }
+        } else {
+            if (lit) { q += lit; if (lit >= avail) avail = 0; else { w >>= 8 * lit; avail -= lit; } }
+            if (avail < 2) refill();
+            off = (uint32_t)w & 0xFFFF; w >>= 16; avail -= 2; q += 2;
+            if (off == 0) { status = 1; break; }
+            if ((uint64_t)off > (uint64_t)op + lit + hist) { status = 1; break; }
+            mlen = token & 15;
+            if (mlen == 15) {
+                mlen += len_bytes(); if (status) break;
+                if (q + 4 >= csize) { status = 1; break; }
+            }
+            mlen += 4;
+            if ((uint64_t)mlen + 5 > (uint64_t)(cap - (op + lit))) { status = 1; break; }
+        }
+        const uint32_t slot = nseq & 63;
+        const bool mine = lane == slot;                  // select, not branch: the loop stays scalar
+        d0 = mine ? (lit_src | ((off & 0xFFu) << 24)) : d0;
+        d1 = mine ? (lit | ((off >> 8) << 24)) : d1;
+        d2 = mine ? op : d2;
+        d3 = mine ? mlen : d3;
+        nseq++;
+        op += lit + mlen;
+        if (slot == 63) publish((nseq >> 6) - 1);
+        if (is_last) break;
+    }
+    // final bookkeeping.  Order matters for the partial last slot: its size must be readable by whoever sees it
+    // published, so totals and `finished` are written BEFORE `produced` is bumped for it (LDS ops of one wave are
+    // performed in order; a copier reads `produced` first, then `finished`).
+    const uint32_t full = nseq >> 6, part = (status == 0) ? (nseq & 63) : 0;
+    if (part) {
+        while (full >= lds_peek(&sh.match_done) + FZ_RING) __builtin_amdgcn_s_sleep(8);
+        sh.ring[full % FZ_RING][lane] = uint4{d0, d1, d2, d3};
+    }
+    sh.total_slots = status ? lds_peek(&sh.produced) : full + (part ? 1u : 0u);       // (all lanes store the same values)
+    sh.last_count = part ? part : 64;
+    sh.out_size = op;
+    sh.status = status ? -1 : 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds_poke(&sh.finished, 1u);
+    if (part) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lds_poke(&sh.produced, full + 1); }
+    if (prof && blockIdx.x == 0 && lane == 0) { prof[0] = clock64() - t_begin; prof[1] = t_ring; prof[2] = nseq; }
+}
+
+// ---------------- copier waves ----------------
+__device__ __forceinline__ void fz_copier(FzShared& sh, const uint8_t* __restrict__ in, uint8_t* out, uint32_t cw /* 0..6 */,
+                                          const uint8_t* safe /* 16 readable bytes */, unsigned long long* prof)
+{
+    const uint32_t lane = lane_id();
+    unsigned long long t_wait_p = 0, t_lit = 0, t_wait_m = 0, t_match = 0, n_slots = 0;
+    auto dump = [&]() { if (prof && blockIdx.x == 0 && lane == 0) { unsigned long long* o = prof + 8 * (cw + 1); o[0] = t_wait_p; o[1] = t_lit; o[2] = t_wait_m; o[3] = t_match; o[4] = n_slots; } };
+    for (uint32_t slot = cw;; slot += FZ_WAVES - 1) {
+        // wait for the slot (or for the end of the block)
+        const unsigned long long c0 = clock64();
+        for (;;) {
+            if (lds_peek(&sh.produced) > slot) break;
+            if (lds_peek(&sh.finished)) { if (lds_peek(&sh.produced) > slot) break; dump(); return; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        const unsigned long long c1 = clock64(); t_wait_p += c1 - c0; n_slots++;
+        const uint4 d = sh.ring[slot % FZ_RING][lane];
+        // descriptors in this slot: 64, except a partial last slot -- which is published only after `finished`
+        uint32_t count = 64;
+        if (lds_peek(&sh.finished) && slot + 1 == lds_peek(&sh.total_slots)) count = lds_peek(&sh.last_count);
+        count = uni(count);
+        const uint32_t vsrc = d.x & 0xFFFFFFu, vlen = d.y & 0xFFFFFFu, vdst = d.z, vml = d.w, voff = (d.x >> 24) | ((d.y >> 24) << 8);
+
+        // ---- (1) literals: no dependencies.  Software pipeline, two jobs per stage, two stages: the loads of the next two
+        // pieces are issued before the stores of the current two, with hand-counted waits (see common.cuh).
+        {
+            uint32_t k = 0, off = 0;                                     // scalar iterator over (descriptor, 1 KiB round)
+            auto next_job = [&]() -> CopyJob {
+                for (;;) {
+                    if (k >= count) return CopyJob{safe, out, 0};
+                    const uint32_t len = __builtin_amdgcn_readlane(vlen, k);
+                    const uint8_t* sp = in + __builtin_amdgcn_readlane(vsrc, k);
+                    uint8_t* dp = out + __builtin_amdgcn_readlane(vdst, k);
+                    if (len < 16) {                                      // tiny run: bytewise, right now
+                        if (lane < len) dp[lane] = sp[lane];
+                        k++; off = 0; continue;
+                    }
+                    uint32_t o = off, n = len - off;
+                    if (n > 1024) n = 1024;
+                    if (n < 16) { o = len - 16; n = 16; }                // ragged end of a long run: overlap backwards
+                    off += 1024;
+                    if (off >= len) { k++; off = 0; }
+                    return CopyJob{sp + o, dp + o, n};
+                }
+            };
+            // ping-pong: set A = (a0,a1 / pa0,pa1), set B = (b0,b1 / pb0,pb1); no register moves between stages
+            CopyJob a0 = next_job(), a1 = next_job(), b0, b1;
+            Piece pa0, pa1, pb0, pb1;
+            job_load(pa0, a0, safe); job_load(pa1, a1, safe);
+            while (a0.n) {
+                b0 = next_job(); b1 = next_job();
+                job_load(pb0, b0, safe); job_load(pb1, b1, safe);
+                job_store(a0, pa0); job_store(a1, pa1);
+                if (b0.n == 0) break;
+                a0 = next_job(); a1 = next_job();
+                job_load(pa0, a0, safe); job_load(pa1, a1, safe);
+                job_store(b0, pb0); job_store(b1, pb1);
+            }
+        }
+        // ---- (2) matches, in stream order, after every earlier slot's matches ----
+        const unsigned long long c2 = clock64(); t_lit += c2 - c1;
+        while (lds_peek(&sh.match_done) < slot) {
+            if ((int32_t)lds_peek((const uint32_t*)&sh.status) < 0) { dump(); return; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        const unsigned long long c3 = clock64(); t_wait_m += c3 - c2;
+        {
+            // Stream-order replay, software-pipelined.  One wave's vector memory operations are performed in issue order,
+            // so a load issued AFTER an earlier match's store instruction sees its bytes.  The pipeline issues the loads
+            // of up to three later matches BEFORE the store of the oldest pending one (a0); that is legal exactly when
+            // their sources end at or below a0's destination (sources always lie below their own destination, and
+            // destinations increase).  A match that fails the test, or is not a single non-overlapping round, ends the
+            // run; the next run (or the generic wave_copy_match) is then issued after all stores, which is always right.
+            uint32_t k = 0;
+            enum : uint32_t { F_OK = 0, F_NONE = 1, F_BLOCKED = 2, F_SLOW = 3 };
+            auto fetch = [&](CopyJob& j, uint32_t limit) -> uint32_t {
+                j = CopyJob{safe, out, 0};
+                for (;;) {
+                    if (k >= count) return F_NONE;
+                    const uint32_t m = __builtin_amdgcn_readlane(vml, k);
+                    if (m == 0) { k++; continue; }                       // the last sequence has no match
+                    const uint32_t o = __builtin_amdgcn_readlane(voff, k);
+                    const uint32_t dm = __builtin_amdgcn_readlane(vdst, k) + __builtin_amdgcn_readlane(vlen, k);
+                    if (!(m >= 16 && m <= 1024 && o >= m)) return F_SLOW;
+                    if (dm - o + m > limit) return F_BLOCKED;
+                    j = CopyJob{out + dm - o, out + dm, m};
+                    k++;
+                    return F_OK;
+                }
+            };
+            for (;;) {
+                CopyJob a0, a1, b0, b1;
+                uint32_t r = fetch(a0, 0xFFFFFFFFu);
+                if (r == F_NONE) break;
+                if (r == F_SLOW) {
+                    const uint32_t m = __builtin_amdgcn_readlane(vml, k), o = __builtin_amdgcn_readlane(voff, k);
+                    const uint32_t dm = __builtin_amdgcn_readlane(vdst, k) + __builtin_amdgcn_readlane(vlen, k);
+                    wave_copy_match(out + dm, o, m);
+                    k++;
+                    continue;
+                }
+                // ping-pong sets A and B; `lim` = destination of the oldest match whose store has not been issued yet
+                Piece pa0, pa1, pb0, pb1;
+                uint32_t lim = (uint32_t)(a0.d - out);
+                r = fetch(a1, lim);
+                job_load(pa0, a0, safe); job_load(pa1, a1, safe);
+                for (;;) {
+                    b0 = CopyJob{safe, out, 0}; b1 = b0;
+                    if (r == F_OK) { r = fetch(b0, lim); if (r == F_OK) r = fetch(b1, lim); }
+                    job_load(pb0, b0, safe); job_load(pb1, b1, safe);
+                    job_store(a0, pa0); job_store(a1, pa1);
+                    if (b0.n == 0) break;
+                    lim = (uint32_t)(b0.d - out);
+                    a0 = CopyJob{safe, out, 0}; a1 = a0;
+                    if (r == F_OK) { r = fetch(a0, lim); if (r == F_OK) r = fetch(a1, lim); }
+                    job_load(pa0, a0, safe); job_load(pa1, a1, safe);
+                    job_store(b0, pb0); job_store(b1, pb1);
+                    if (a0.n == 0) break;
+                    lim = (uint32_t)(a0.d - out);
+                }
+            }
+        }
+        // ---- (3) everything this slot wrote is in memory: let the next slot's matches go ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_poke(&sh.match_done, slot + 1);
+        t_match += clock64() - c3;
+    }
+}
+
+// Decode one compressed block with the whole workgroup; returns decoded size or -1 (same value in all threads).
+__device__ __forceinline__ int32_t fz_decode_block(FzShared& sh, const uint8_t* __restrict__ in, uint32_t csize, uint8_t* out, uint32_t cap, uint64_t hist,
+                                                   const uint8_t* safe, unsigned long long* prof)
+{
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    __syncthreads();                                                     // previous block's LDS state is dead
+    if (threadIdx.x == 0) { sh.produced = 0; sh.total_slots = 0; sh.last_count = 64; sh.finished = 0; sh.match_done = 0; sh.status = 0; sh.out_size = 0; }
+    __syncthreads();
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);                                   // the serial chain: win issue arbitration against the 7 copier waves of this SIMD
+        fz_parser(sh, in, csize, cap, hist, prof);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    else fz_copier(sh, in, out, wave - 1, safe, prof);
+    __syncthreads();                                                     // all copies of this block are issued and complete
+    const int32_t st = (int32_t)uni((uint32_t)sh.status);
+    const uint32_t osz = uni(sh.out_size);
+    return st < 0 ? -1 : (int32_t)osz;
+}
+
+__global__ __launch_bounds__(64 * FZ_WAVES, 8) void k_decode_blocks_fused(const uint8_t* __restrict__ frame, uint8_t* dst, uint64_t dst_cap,
+                                                                          BlockOut* __restrict__ table, const ResultRec* __restrict__ res,
+                                                                          uint32_t n_max, uint32_t linked, uint32_t block_size, uint64_t hist0,
+                                                                          unsigned long long* prof)
+{
+    __shared__ FzShared sh;
+    if (res->status != ST_OK) return;
+    const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    const uint32_t tid = threadIdx.x;
+    if (linked && blockIdx.x != 0) return;
+    uint32_t b = linked ? 0u : blockIdx.x;
+    const uint32_t b_end = linked ? n : (b < n ? b + 1 : b);
+    uint64_t out = 0;
+    for (; b < b_end; b++) {
+        const BlockOut e = table[b];
+        const uint32_t csz = e.word & 0x7FFFFFFFu;
+        const uint64_t at = linked ? out : e.dst_off;
+        const uint32_t room = linked ? (uint32_t)((dst_cap - out < block_size) ? dst_cap - out : block_size) : e.dst_size;
+        int32_t got;
+        if (e.word >> 31) {                                              // stored block: all waves copy a slice
+            if (csz > room) got = -2;
+            else {
+                const uint32_t per = (((csz + FZ_WAVES - 1) / FZ_WAVES) + 15) & ~15u;
+                const uint32_t a = (tid >> 6) * per;
+                if (a < csz) wave_copy_disjoint(dst + at + a, frame + e.src_off + a, (csz - a < per) ? csz - a : per);
+                got = (int32_t)csz;
+            }
+        } else {
+            got = fz_decode_block(sh, frame + e.src_off, csz, dst + at, room, linked ? out + hist0 : 0, frame, prof);
+        }
+        if (tid == 0) { table[b].dst_off = at; table[b].dst_size = (uint32_t)got; }
+        if (got < 0) {
+            if (linked) for (uint32_t k = b + 1 + tid; k < n; k += 64 * FZ_WAVES) table[k].dst_size = 0;
+            break;
+        }
+        out += (uint32_t)got;
+        __syncthreads();
+    }
+}
+
+}  // namespace lz4f

@@ -141,6 +141,20 @@ size_t lz4f_mi355x_engine::sync()
 }
 
 // ------------------------------------------------------------------------------------------------
+// developer aid: cycle counters of workgroup 0 (LZ4F_MI355X_PROF=1), read back with lz4f_mi355x_debug_prof
+static unsigned long long* g_prof = nullptr;
+static unsigned long long* prof_buf()
+{
+    if (!g_prof) { if (hipMalloc(&g_prof, 1024) != hipSuccess) return nullptr; (void)hipMemset(g_prof, 0, 1024); }
+    return g_prof;
+}
+extern "C" __attribute__((visibility("default"))) int lz4f_mi355x_debug_prof(unsigned long long* out128)
+{
+    if (!g_prof) return 1;
+    (void)hipDeviceSynchronize();
+    return hipMemcpy(out128, g_prof, 1024, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+}
+
 size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst, uint64_t dst_cap,
                                            lz4f_mi355x_result* d_res, lz4f_mi355x_block* d_table)
 {
@@ -233,9 +247,15 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         }
         tick(6, false);
         // one workgroup (8 waves) per block when blocks are few and large, one wave per block otherwise
-        bool two = j.linked || j.block_size >= (256u << 10);
-        if (const char* dv = getenv("LZ4F_MI355X_DECODE")) two = (dv[0] == '2');
-        if (two) {
+        // large blocks / linked frames: fused parse+copy workgroups ('f', default), or the two-kernel variant ('2');
+        // small independent blocks: one wave per block ('1')
+        char mode = (j.linked || j.block_size >= (256u << 10)) ? 'f' : '1';
+        if (const char* dv = getenv("LZ4F_MI355X_DECODE")) mode = dv[0];
+        if (mode == 'f') {
+            hipLaunchKernelGGL(k_decode_blocks_fused, dim3(j.linked ? 1u : n_max), dim3(64 * FZ_WAVES), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
+                               (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, j.hist0,
+                               (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr));
+        } else if (mode == '2') {
             const size_t per_block = (size_t)j.block_size / 4 + 2;
             if (desc.ensure((size_t)n_max * per_block * sizeof(SeqDesc)) || seqcnt.ensure((size_t)n_max * 8 + 64)) return make_err(LZ4F_ERROR_allocation_failed);
             uint32_t* cnt = (uint32_t*)seqcnt.p; uint32_t* osz = cnt + n_max;

@@ -8,6 +8,7 @@
 #include "common.cuh"
 #include "decode.cuh"
 #include "decode_2k.cuh"
+#include "decode_fused.cuh"
 #include "encode.cuh"
 
 namespace lz4f {
