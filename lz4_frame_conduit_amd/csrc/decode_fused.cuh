@@ -25,7 +25,7 @@ namespace lz4f {
 
 constexpr int      FZ_WAVES = 8;
 constexpr uint32_t FZ_STAGE = 8192;
-constexpr uint32_t FZ_OVER = 64;
+constexpr uint32_t FZ_OVER = 576;                // >= the parser's 520-byte register window + 8
 constexpr uint32_t FZ_RING = 8;                 // slots of 64 descriptors
 
 struct alignas(16) FzShared {
@@ -60,21 +60,6 @@ __device__ __forceinline__ void fz_stage_issue(uint8_t* slot, const uint8_t* __r
     if (lane < span - tail0) slot[tail0 + lane] = in[base + tail0 + lane];
 }
 
-__device__ __forceinline__ uint64_t fz_fetch8(const uint8_t* stages, uint32_t q)
-{
-    const uint32_t s = q / FZ_STAGE;
-    const uint32_t o = q - s * FZ_STAGE;
-    const uint32_t addr = (uint32_t)(uintptr_t)(lptr_t)(stages + (s & 1) * (FZ_STAGE + FZ_OVER)) + (o & ~3u);
-    uint64_t w01; uint32_t w2;
-    // inline asm: see pk_fetch8 (decode_2k.cuh) -- keeps hipcc from waiting on the pending stage prefetch
-    asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read_b32 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(w01), "=&v"(w2) : "v"(addr) : "memory");
-    const uint64_t lo = uni64(w01);
-    const uint32_t hi = uni(w2);
-    const uint32_t shv = (o & 3u) * 8;
-    return (lo >> shv) | (((uint64_t)hi << 32) << (32 - shv));
-}
-
 // ---------------- parser wave ----------------
 __device__ __forceinline__ void fz_parser(FzShared& sh, const uint8_t* __restrict__ in, uint32_t csize, uint32_t cap, uint64_t hist,
                                           unsigned long long* prof)
@@ -83,8 +68,7 @@ __device__ __forceinline__ void fz_parser(FzShared& sh, const uint8_t* __restric
     const uint32_t lane = lane_id();
     uint8_t* stages = &sh.stage[0][0];
     uint32_t nseq = 0, status = 0;
-    uint32_t q = 0, op = 0;
-    uint64_t w = 0; uint32_t avail = 0;
+    uint32_t op = 0;
     int32_t  cur = -1;
     uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
 
@@ -93,29 +77,46 @@ __device__ __forceinline__ void fz_parser(FzShared& sh, const uint8_t* __restric
     auto need = [&](uint32_t qq) {
         const int32_t s = (int32_t)(qq / FZ_STAGE);
         if (s == cur) return;
-        if (s != cur + 1) {                                                      // a jump over a long literal run: load it now
+        // next stage in sequence: its DMA is in flight -> wait, then start the one after.  A jump further ahead (a very
+        // long literal run) first has to start its own stage.
+#pragma unroll 1
+        for (int32_t it = (s == cur + 1) ? 1 : 0; it < 2; it++) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            fz_stage_issue(stages + (uint32_t)(s & 1) * (FZ_STAGE + FZ_OVER), in, csize, (uint32_t)s);
+            fz_stage_issue(stages + (uint32_t)((s + it) & 1) * (FZ_STAGE + FZ_OVER), in, csize, (uint32_t)(s + it));
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         cur = s;
-        fz_stage_issue(stages + (uint32_t)((s + 1) & 1) * (FZ_STAGE + FZ_OVER), in, csize, (uint32_t)s + 1);
     };
-    auto refill = [&]() { need(q); w = fz_fetch8(stages, q); avail = 8; };
-    auto len_bytes = [&]() -> uint32_t {
+    // Register window: lane l holds the 16 payload bytes at wb + 8*l, so any 8-byte read inside [wb, wb+512) is four
+    // v_readlane + a funnel shift, no LDS round trip.  A miss (the jump over a long literal run; none for dozens of
+    // short sequences) reloads the window at the wanted position with one ds_read2_b64.
+    typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+    v4u_t win = {0u, 0u, 0u, 0u};
+    uint32_t wb = 0xFFFFFC00u;                       // nothing loaded yet: every position misses
+    auto reload = [&](uint32_t qq) {
+        need(qq);
+        const uint32_t s = qq / FZ_STAGE;
+        const uint32_t o = (qq - s * FZ_STAGE) & ~7u;
+        const uint32_t addr = (uint32_t)(uintptr_t)(lptr_t)(stages + (s & 1) * (FZ_STAGE + FZ_OVER)) + o + 8u * lane;
+        // inline asm: keeps hipcc from draining vmcnt (the pending stage prefetch) before this LDS read
+        asm volatile("ds_read2_b64 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(win) : "v"(addr) : "memory");
+        wb = qq & ~7u;
+    };
+    auto fetch = [&](uint32_t qq) -> uint64_t {
+        uint32_t rel = qq - wb;
+        if (rel >= 504u) { reload(qq); rel = qq - wb; }                    // lanes 0..62 serve reads at rel 0..503
+        const uint32_t l = rel >> 3, sh8 = (rel & 7u) * 8u;
+        const uint64_t lo = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(win.x, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(win.y, l) << 32);
+        const uint64_t hi = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(win.z, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(win.w, l) << 32);
+        return (lo >> sh8) | ((hi << 1) << (63u - sh8));
+    };
+    // length bytes that do not end inside the 8-byte read that found them (runs of >= 6 x 0xFF): rare, byte by byte
+    auto ext_slow = [&](uint32_t pos, uint32_t& after) -> uint32_t {
         uint32_t add = 0;
         for (;;) {
-            if (avail == 0) refill();
-            const uint64_t inv = ~w;
-            const uint32_t k = inv ? (uint32_t)(__builtin_ctzll(inv) >> 3) : 8u;
-            if (k < avail) {
-                add += 255u * k + (uint32_t)((w >> (8 * k)) & 0xFF);
-                const uint32_t used = k + 1;
-                w = used < 8 ? (w >> (8 * used)) : 0; avail -= used; q += used;
-                return add;
-            }
-            add += 255u * avail; q += avail; avail = 0;
-            if (add > 0x7FFF0000u || q >= csize) { status = 1; return add; }
+            if (pos >= csize || add > 0x7FFF0000u) { status = 1; after = pos; return add; }
+            const uint32_t b = uni((uint32_t)in[pos]);
+            add += b; pos++;
+            if (b != 255) { after = pos; return add; }
         }
     };
     // publish the gathered descriptors as ring slot number `slot_idx`
@@ -128,44 +129,72 @@ __device__ __forceinline__ void fz_parser(FzShared& sh, const uint8_t* __restric
         lds_poke(&sh.produced, slot_idx + 1);
     };
 
-    while (status == 0) {
-        if (q >= csize) { status = 1; break; }
-        if (avail == 0) refill();
-        const uint32_t token = (uint32_t)w & 0xFF; w >>= 8; avail--; q++;
+    // The loop is written for the scalar unit: every quantity is wave-uniform, rule violations are OR-ed into `bad`
+    // and tested once per sequence, and the only branches on the usual path are "window miss", "last sequence" and
+    // "slot full".  (Early exits in the middle of the body cost more in control-flow bookkeeping than the work itself.)
+    uint32_t pos = 0;
+    uint32_t fin = status;                                                  // bit 0 error, bit 1 last sequence done
+    const uint32_t hist_reach = hist > 65536 ? 65536u : (uint32_t)hist;     // offsets are <= 65535: more history is not distinguishable
+    while (fin == 0) {
+        // ---- token, literal length ----
+        const uint64_t w = fetch(pos);
+        const uint32_t token = (uint32_t)w & 0xFF;
         uint32_t lit = token >> 4;
-        if (lit == 15) { lit += len_bytes(); if (status) break; }
-        if (q > csize) { status = 1; break; }
-        const uint32_t in_left = csize - q, out_left = cap - op;
-        const uint32_t lit_src = q;
-        uint32_t mlen = 0, off = 0;
-        const bool is_last = (uint64_t)lit + 12 > out_left || (uint64_t)lit + 8 > in_left;
-        if (is_last) {
-            if (lit != in_left || lit > out_left) { status = 1; break; }
-        } else {
-            if (lit) { q += lit; if (lit >= avail) avail = 0; else { w >>= 8 * lit; avail -= lit; } }
-            if (avail < 2) refill();
-            off = (uint32_t)w & 0xFFFF; w >>= 16; avail -= 2; q += 2;
-            if (off == 0) { status = 1; break; }
-            if ((uint64_t)off > (uint64_t)op + lit + hist) { status = 1; break; }
-            mlen = token & 15;
-            if (mlen == 15) {
-                mlen += len_bytes(); if (status) break;
-                if (q + 4 >= csize) { status = 1; break; }
-            }
-            mlen += 4;
-            if ((uint64_t)mlen + 5 > (uint64_t)(cap - (op + lit))) { status = 1; break; }
+        uint32_t p = pos + 1;                                                // first literal byte
+        uint32_t bad = 0;
+        {
+            const uint64_t x = w >> 8;                                       // 7 candidate length bytes, top byte 0 (never 0xFF)
+            const uint32_t f = (uint32_t)__builtin_ctzll(~x);
+            const uint32_t k = f >> 3;
+            const uint32_t ext = 255u * k + (uint32_t)((x >> (f & 56u)) & 0xFF);
+            const bool is15 = lit == 15;
+            lit = is15 ? 15u + ext : lit;
+            p = is15 ? pos + 2 + k : p;
+            if (is15 && k == 7) { lit = 15u + ext_slow(pos + 1, p); bad |= status; }
         }
-        const uint32_t slot = nseq & 63;
-        const bool mine = lane == slot;                  // select, not branch: the loop stays scalar
-        d0 = mine ? (lit_src | ((off & 0xFFu) << 24)) : d0;
-        d1 = mine ? (lit | ((off >> 8) << 24)) : d1;
-        d2 = mine ? op : d2;
-        d3 = mine ? mlen : d3;
-        nseq++;
-        op += lit + mlen;
-        if (slot == 63) publish((nseq >> 6) - 1);
-        if (is_last) break;
+        bad |= p > csize ? 1u : 0u;
+        const uint32_t in_left = csize - p;
+        const uint32_t lit_src = p;
+        const bool is_last = lit > in_left || lit + 8 > in_left || lit + 12 > cap - op;   // lit < 2^31
+        uint32_t mlen = 0, off = 0, npos = pos;
+        if (!is_last) {
+            // ---- offset, match length ----
+            const uint32_t qo = p + lit;
+            const uint64_t w2 = fetch(qo);
+            off = (uint32_t)w2 & 0xFFFF;
+            bad |= off == 0 ? 1u : 0u;
+            bad |= off > op + lit + hist_reach ? 1u : 0u;
+            const uint64_t x = w2 >> 16;                                     // 6 candidate length bytes
+            const uint32_t f = (uint32_t)__builtin_ctzll(~x);
+            const uint32_t k = f >> 3;
+            const uint32_t ext = 255u * k + (uint32_t)((x >> (f & 56u)) & 0xFF);
+            const bool is15 = (token & 15) == 15;
+            mlen = is15 ? 15u + ext : (token & 15);
+            npos = is15 ? qo + 3 + k : qo + 2;
+            if (is15 && k == 6) { mlen = 15u + ext_slow(qo + 2, npos); bad |= status; }
+            bad |= (is15 && npos + 4 >= csize) ? 1u : 0u;
+            mlen += 4;
+            bad |= mlen + 5 > cap - (op + lit) ? 1u : 0u;
+        } else {
+            bad |= lit != in_left ? 1u : 0u;
+            bad |= lit > cap - op ? 1u : 0u;
+        }
+        fin |= bad;
+        if (fin == 0) {                                                      // a good sequence: record it
+            const uint32_t slot = nseq & 63;
+            const bool mine = lane == slot;                                  // select, not branch: the loop stays scalar
+            d0 = mine ? (lit_src | ((off & 0xFFu) << 24)) : d0;
+            d1 = mine ? (lit | ((off >> 8) << 24)) : d1;
+            d2 = mine ? op : d2;
+            d3 = mine ? mlen : d3;
+            nseq++;
+            op += lit + mlen;
+            if (slot == 63) publish((nseq >> 6) - 1);
+            pos = npos;
+            fin |= is_last ? 2u : (pos >= csize ? 1u : 0u);
+        }
     }
+    if (fin & 1u) status = 1;
     // final bookkeeping.  Order matters for the partial last slot: its size must be readable by whoever sees it
     // published, so totals and `finished` are written BEFORE `produced` is bumped for it (LDS ops of one wave are
     // performed in order; a copier reads `produced` first, then `finished`).
