@@ -156,3 +156,18 @@ def test_no_gpu_fails_loudly(L):
     h = ctypes.c_void_p()
     r = L.lz4f_mi355x_engine_create(ctypes.byref(h), 0, None, 0)
     assert L.LZ4F_isError(r)
+
+
+def test_cli_builds_and_fails_loudly_without_gpu(L):
+    """mi355x-lz4c (app/Main.hs equivalent) is an ordinary client of the C ABI: it must exist next to the
+    library, print usage, and - without a device - exit non-zero with an error instead of emitting anything."""
+    import os
+    import subprocess
+    cli = os.path.join(os.path.dirname(_ffi.LIB_PATH), "mi355x-lz4c")
+    assert os.path.exists(cli)
+    assert b"Usage: mi355x-lz4c" in subprocess.run([cli, "--help"], stdout=subprocess.PIPE, check=True, timeout=60).stdout
+    assert subprocess.run([cli, "--bogus"], stderr=subprocess.PIPE, timeout=60).returncode == 2
+    if L.lz4f_mi355x_device_count() > 0:
+        pytest.skip("a GPU is present")
+    p = subprocess.run([cli], input=b"x" * 100000, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert p.returncode == 1 and b"ERROR_GENERIC" in p.stderr

@@ -288,3 +288,36 @@ def test_full_size_properties_1gib(L):
     assert oracle.xxh32(a.tobytes()) == oracle.xxh32(b.tobytes())
     assert int(a[0]) == oracle.xxh32(src[:1 << 22].cpu().numpy())
     eng.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# the command-line driver (app/Main.hs equivalent) exchanges frames with liblz4 in both directions
+def test_cli_interop_with_liblz4_frames(L, golden, named_inputs, tmp_path):
+    import os
+    import subprocess
+    cli = os.path.join(os.path.dirname(_ffi.LIB_PATH), "mi355x-lz4c")
+    assert os.path.exists(cli), "csrc/Makefile builds it next to the library"
+    run = lambda args, **kw: subprocess.run([cli] + args, check=True, timeout=120, **kw)
+    # (1) frames written by liblz4 (committed golden files) -> `mi355x-lz4c -d`, file arguments and stdin/stdout
+    for key in ("ints/default", "rep42/default", "text512k/indep64k_bck"):
+        ent = golden["frames"][key]
+        f_in = tmp_path / "in.lz4"; f_out = tmp_path / "out.bin"
+        f_in.write_bytes(golden_file(ent["file"]))
+        run(["-d", str(f_in), str(f_out)])
+        assert sha(f_out.read_bytes()) == ent["input_sha256"], key
+        piped = run(["-d", "--batch", "0"], input=golden_file(ent["file"]), stdout=subprocess.PIPE).stdout      # the reference's conduit verbatim
+        assert sha(piped) == ent["input_sha256"], key
+    # (2) `mi355x-lz4c` output is a frame the oracle (bit-exact with liblz4's decoder) accepts, for the CLI's option shapes
+    data = named_inputs["synth50_2m"] + named_inputs["text512k"]
+    f_src = tmp_path / "src.bin"; f_src.write_bytes(data)
+    for opts in ([], ["--batch", "0"], ["-B7", "-BI", "--content-checksum"], ["-B5", "-BD", "--block-checksum"], ["-B4", "-BI", "--batch", "1"]):
+        f_lz = tmp_path / "x.lz4"
+        run(opts + [str(f_src), str(f_lz)])
+        frame = f_lz.read_bytes()
+        assert frame[:4] == bytes.fromhex("04224d18")
+        assert oracle.decompress_frame(frame, len(data) + 8)[0] == data, opts
+        assert len(frame) < len(data)
+    # (3) errors are reported, not swallowed: a truncated frame fails with the reference's message
+    bad = golden_file(golden["frames"]["ints/default"]["file"])[:-9]
+    p = subprocess.run([cli, "-d"], input=bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+    assert p.returncode == 1 and b"mi355x-lz4c:" in p.stderr
