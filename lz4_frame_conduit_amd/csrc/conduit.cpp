@@ -234,28 +234,43 @@ void decompressBatched(const Await& await, const Yield& yield)
     while (await(bs)) frame.insert(frame.end(), bs.data, bs.data + bs.size);
     if (frame.size() < 5)
         throw std::runtime_error("lz4 decompress error: not enough bytes for header; expected 5, got " + std::to_string(frame.size()));
-    // capacity: contentSize when declared, else blocks * maxBlockSize from a walk of the size words
-    ParsedHeader ph;
-    if ((frame.size() >= 4) && ((uint32_t)frame[0] | (frame[1] << 8) | (frame[2] << 16) | ((uint32_t)frame[3] << 24)) != 0x184D2204u) {
+    // Unlike `decompress` (which mirrors the reference and stops after the first frame, Appendix C quirk 3, and cannot read
+    // dictID headers, quirk 2), this walks the whole stream the way LZ4F_decompress called in a loop would: skippable
+    // frames are skipped, concatenated frames are all decoded, any header the format allows is accepted.
+    auto le32 = [&](size_t at) { return (uint32_t)frame[at] | ((uint32_t)frame[at + 1] << 8) | ((uint32_t)frame[at + 2] << 16) | ((uint32_t)frame[at + 3] << 24); };
+    size_t at = 0;
+    std::vector<uint8_t> out;
+    while (at < frame.size()) {
+        const uint8_t* f = frame.data() + at;
+        const size_t left = frame.size() - at;
+        if (left < 4) handleLz4Error(make_err(LZ4F_ERROR_frameHeader_incomplete));
+        const uint32_t magic = le32(at);
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {                        // skippable: magic, u32 size, payload
+            if (left < 8) handleLz4Error(make_err(LZ4F_ERROR_frameHeader_incomplete));
+            const size_t sz = le32(at + 4);
+            if (left - 8 < sz) throw std::runtime_error("lz4 decompress error: stream ended before EndMark");
+            at += 8 + sz;
+            continue;
+        }
+        ParsedHeader ph;
+        handleLz4Error(parse_frame_header(f, left, &ph));                  // frameType_unknown for anything else
+        // capacity: blocks * maxBlockSize from a walk of the size words
+        size_t cap = 0, pos = ph.header_size;
+        for (;;) {
+            if (left - pos < 4) throw std::runtime_error("lz4 decompress error: stream ended before EndMark");
+            const uint32_t w = le32(at + pos);
+            if (w == 0) break;
+            const size_t step = 4 + (size_t)(w & 0x7FFFFFFFu) + (ph.info.blockChecksumFlag ? 4 : 0);
+            if (left - pos < step) throw std::runtime_error("lz4 decompress error: stream ended before EndMark");
+            pos += step;
+            cap += ph.max_block;
+        }
+        out.resize(cap ? cap : 1);
         size_t used = 0;
-        handleLz4Error(lz4f_mi355x_decompressFrame(nullptr, 0, frame.data(), frame.size(), &used));
-        return;
+        const size_t n = handleLz4Error(lz4f_mi355x_decompressFrame(out.data(), cap, f, left, &used));
+        yield(Slice{out.data(), n});
+        at += used;
     }
-    handleLz4Error(parse_frame_header(frame.data(), frame.size(), &ph));
-    size_t cap = 0, pos = ph.header_size;
-    for (;;) {
-        if (frame.size() - pos < 4) throw std::runtime_error("lz4 decompress error: stream ended before EndMark");
-        const uint32_t w = (uint32_t)frame[pos] | (frame[pos + 1] << 8) | (frame[pos + 2] << 16) | ((uint32_t)frame[pos + 3] << 24);
-        if (w == 0) break;
-        const size_t step = 4 + (size_t)(w & 0x7FFFFFFFu) + (ph.info.blockChecksumFlag ? 4 : 0);
-        if (frame.size() - pos < step) throw std::runtime_error("lz4 decompress error: stream ended before EndMark");
-        pos += step;
-        cap += ph.max_block;
-    }
-    std::vector<uint8_t> out(cap ? cap : 1);
-    size_t used = 0;
-    const size_t n = handleLz4Error(lz4f_mi355x_decompressFrame(out.data(), cap, frame.data(), frame.size(), &used));
-    yield(Slice{out.data(), n});
 }
 
 }  // namespace conduit

@@ -321,3 +321,42 @@ def test_cli_interop_with_liblz4_frames(L, golden, named_inputs, tmp_path):
     bad = golden_file(golden["frames"]["ints/default"]["file"])[:-9]
     p = subprocess.run([cli, "-d"], input=bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
     assert p.returncode == 1 and b"mi355x-lz4c:" in p.stderr
+
+
+# ------------------------------------------------------------------------------------------------
+# decoder completeness around the hot loop -- skippable frames, concatenated frames, contentSize / dictID
+# headers (the reference's own `decompress` cannot read a dictID header, Appendix C quirk 2), stored blocks.
+def test_batched_decoder_walks_whole_streams(L, golden, named_inputs):
+    text = named_inputs["text512k"]
+    rnd = named_inputs["random10m"][:300000]                              # stored (raw) blocks
+    skip = bytes.fromhex("502a4d18") + (5).to_bytes(4, "little") + b"hello"
+    frames = {
+        "plain": (oracle.conduit_compress(text, oracle.mkprefs(4, 1, 1, 0, 0, 0, 0), 16384), text),
+        "csize+dictid": (oracle.conduit_compress(text, oracle.mkprefs(5, 0, 1, 1, len(text), 77, 0), 16384), text),
+        "stored+dictid": (oracle.conduit_compress(rnd, oracle.mkprefs(4, 1, 0, 0, 0, 9, 0), 16384), rnd),
+        "empty": (oracle.conduit_compress(b"", oracle.mkprefs(4, 1, 1, 0, 0, 0, 0), 16384), b""),
+    }
+    for name, (fr, want) in frames.items():
+        assert oracle.decompress_frame(fr, len(want) + 8)[0] == want
+    streams = {
+        "single": ["csize+dictid"], "concat": ["plain", "stored+dictid", "csize+dictid"], "skip first": ["SKIP", "plain"],
+        "skip between and last": ["plain", "SKIP", "empty", "stored+dictid", "SKIP"],
+    }
+    for label, parts in streams.items():
+        stream = b"".join(skip if p == "SKIP" else frames[p][0] for p in parts)
+        want = b"".join(b"" if p == "SKIP" else frames[p][1] for p in parts)
+        for chunks in ([stream], [stream[:1], stream[1:5], stream[5:9], stream[9:70000], stream[70000:]]):
+            assert b"".join(conduit.decompressBatched(chunks)) == want, label
+    # what must still fail, with liblz4's names
+    with pytest.raises(conduit.Lz4FrameError, match="ERROR_frameType_unknown"):
+        conduit.decompressBatched([frames["plain"][0] + b"\x01\x02\x03\x04\x05\x06\x07\x08"])
+    with pytest.raises(conduit.Lz4FrameError, match="stream ended before EndMark"):
+        conduit.decompressBatched([frames["plain"][0][:-20]])
+    bad = bytearray(frames["csize+dictid"][0]); bad[6] ^= 1                # contentSize field: header checksum catches it
+    with pytest.raises(conduit.Lz4FrameError, match="ERROR_headerChecksum_invalid"):
+        conduit.decompressBatched([bytes(bad)])
+    wrong = oracle.conduit_compress(text, oracle.mkprefs(4, 1, 0, 0, len(text), 0, 0), 16384)
+    short = oracle.conduit_compress(text[:-1], oracle.mkprefs(4, 1, 0, 0, 0, 0, 0), 16384)
+    forged = wrong[:15] + short[7:]                                        # header promises one byte more than the blocks hold
+    with pytest.raises(conduit.Lz4FrameError, match="ERROR_frameSize_wrong"):
+        conduit.decompressBatched([forged])
