@@ -27,6 +27,7 @@ constexpr int      FZ_WAVES = 8;
 constexpr uint32_t FZ_STAGE = 8192;
 constexpr uint32_t FZ_OVER = 576;                // >= the parser's 520-byte register window + 8
 constexpr uint32_t FZ_RING = 8;                 // slots of 64 descriptors
+constexpr int      FZ_MATCH_SET = 3;            // match copies per register set (two sets in flight)
 
 struct alignas(16) FzShared {
     uint4    ring[FZ_RING][64];
@@ -229,6 +230,7 @@ __device__ __forceinline__ void fz_copier(FzShared& sh, const uint8_t* __restric
             __builtin_amdgcn_s_sleep(4);
         }
         const unsigned long long c1 = clock64(); t_wait_p += c1 - c0; n_slots++;
+        __builtin_amdgcn_s_setprio(1);                                       // copying beats polling
         const uint4 d = sh.ring[slot % FZ_RING][lane];
         // descriptors in this slot: 64, except a partial last slot -- which is published only after `finished`
         uint32_t count = 64;
@@ -274,11 +276,13 @@ __device__ __forceinline__ void fz_copier(FzShared& sh, const uint8_t* __restric
         }
         // ---- (2) matches, in stream order, after every earlier slot's matches ----
         const unsigned long long c2 = clock64(); t_lit += c2 - c1;
+        __builtin_amdgcn_s_setprio(0);
         while (lds_peek(&sh.match_done) < slot) {
             if ((int32_t)lds_peek((const uint32_t*)&sh.status) < 0) { dump(); return; }
             __builtin_amdgcn_s_sleep(2);
         }
         const unsigned long long c3 = clock64(); t_wait_m += c3 - c2;
+        __builtin_amdgcn_s_setprio(2);                                       // the match phases form the second serial chain of a block
         {
             // Stream-order replay, software-pipelined.  One wave's vector memory operations are performed in issue order,
             // so a load issued AFTER an earlier match's store instruction sees its bytes.  The pipeline issues the loads
@@ -303,9 +307,10 @@ __device__ __forceinline__ void fz_copier(FzShared& sh, const uint8_t* __restric
                     return F_OK;
                 }
             };
+            constexpr int NJ = FZ_MATCH_SET;                         // jobs per register set: 2 sets -> 2*NJ copies in flight
             for (;;) {
-                CopyJob a0, a1, b0, b1;
-                uint32_t r = fetch(a0, 0xFFFFFFFFu);
+                CopyJob A[NJ], B[NJ];
+                uint32_t r = fetch(A[0], 0xFFFFFFFFu);
                 if (r == F_NONE) break;
                 if (r == F_SLOW) {
                     const uint32_t m = __builtin_amdgcn_readlane(vml, k), o = __builtin_amdgcn_readlane(voff, k);
@@ -315,29 +320,36 @@ __device__ __forceinline__ void fz_copier(FzShared& sh, const uint8_t* __restric
                     continue;
                 }
                 // ping-pong sets A and B; `lim` = destination of the oldest match whose store has not been issued yet
-                Piece pa0, pa1, pb0, pb1;
-                uint32_t lim = (uint32_t)(a0.d - out);
-                r = fetch(a1, lim);
-                job_load(pa0, a0, safe); job_load(pa1, a1, safe);
+                Piece PA[NJ], PB[NJ];
+                uint32_t lim = (uint32_t)(A[0].d - out);
+#pragma unroll
+                for (int i = 1; i < NJ; i++) { A[i] = CopyJob{safe, out, 0}; if (r == F_OK) r = fetch(A[i], lim); }
+#pragma unroll
+                for (int i = 0; i < NJ; i++) job_load(PA[i], A[i], safe);
                 for (;;) {
-                    b0 = CopyJob{safe, out, 0}; b1 = b0;
-                    if (r == F_OK) { r = fetch(b0, lim); if (r == F_OK) r = fetch(b1, lim); }
-                    job_load(pb0, b0, safe); job_load(pb1, b1, safe);
-                    job_store(a0, pa0); job_store(a1, pa1);
-                    if (b0.n == 0) break;
-                    lim = (uint32_t)(b0.d - out);
-                    a0 = CopyJob{safe, out, 0}; a1 = a0;
-                    if (r == F_OK) { r = fetch(a0, lim); if (r == F_OK) r = fetch(a1, lim); }
-                    job_load(pa0, a0, safe); job_load(pa1, a1, safe);
-                    job_store(b0, pb0); job_store(b1, pb1);
-                    if (a0.n == 0) break;
-                    lim = (uint32_t)(a0.d - out);
+#pragma unroll
+                    for (int i = 0; i < NJ; i++) { B[i] = CopyJob{safe, out, 0}; if (r == F_OK) r = fetch(B[i], lim); }
+#pragma unroll
+                    for (int i = 0; i < NJ; i++) job_load(PB[i], B[i], safe);
+#pragma unroll
+                    for (int i = 0; i < NJ; i++) job_store(A[i], PA[i]);
+                    if (B[0].n == 0) break;
+                    lim = (uint32_t)(B[0].d - out);
+#pragma unroll
+                    for (int i = 0; i < NJ; i++) { A[i] = CopyJob{safe, out, 0}; if (r == F_OK) r = fetch(A[i], lim); }
+#pragma unroll
+                    for (int i = 0; i < NJ; i++) job_load(PA[i], A[i], safe);
+#pragma unroll
+                    for (int i = 0; i < NJ; i++) job_store(B[i], PB[i]);
+                    if (A[0].n == 0) break;
+                    lim = (uint32_t)(A[0].d - out);
                 }
             }
         }
         // ---- (3) everything this slot wrote is in memory: let the next slot's matches go ----
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_poke(&sh.match_done, slot + 1);
+        __builtin_amdgcn_s_setprio(0);
         t_match += clock64() - c3;
     }
 }
