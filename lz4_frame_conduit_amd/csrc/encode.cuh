@@ -191,28 +191,38 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
             const bool okB = actB && tB == tgB && dB != 0 && dB <= pB;
             const uint32_t candB = pB - dB;
             const uint32_t ipC = ipB + WAVE * stepB, stepC = stepB + 1;
-            // candidate bytes are fetched only when some lane passed the tag filter (wave-uniform branches: in literal
-            // regions almost every step skips the gather altogether)
-            uint32_t cseqA = ~seqA, cseqB = ~seqB;
-            const uint64_t candsA = __ballot(okA), candsB = __ballot(okB);
-            if (candsA) cseqA = ld32(base + (okA ? candA : 0u));
-            if (candsB) cseqB = ld32(base + (okB ? candB : 0u));
-            // ---- resolve A, then B ----
-            uint64_t hits = __ballot(okA && cseqA == seqA);
-            uint32_t p_hit = pA, cand_hit = candA;
-            bool hitB = false;
-            if (hits == 0) {
-                hits = __ballot(okB && cseqB == seqB);
-                if (hits == 0) {                                                    // both missed: advance two steps, top up the queue
-                    ip = ipC; step = stepC;
-                    s0 = s2; s1 = s3; s2 = s4; s3 = s5;
-                    s4 = stream(ipN, stepN); ipN += WAVE * stepN; stepN++;
-                    s5 = stream(ipN, stepN); ipN += WAVE * stepN; stepN++;
-                    continue;
-                }
-                hitB = true; p_hit = pB; cand_hit = candB;
+            // A candidate is looked at in memory only when its lane passed the 20-bit tag filter (in literal regions almost
+            // every step skips memory altogether), and then verification and extension are ONE round trip: the wave loads
+            // the 64 bytes before and the 512 bytes from the probe position itself, on both sides; the candidate is a match
+            // iff the first four bytes agree.  (A separate 4-byte gather first would cost a second trip on every match.)
+            uint64_t cA = __ballot(okA), cB = __ballot(okB);
+            bool hitB = false, found = false;
+            uint32_t L = 0, mp = 0, mc = 0, dist = 0, room = 0;
+            const uint32_t kb = lane + 1;
+            uint8_t bb0 = 0, bb1 = 1;
+            uint64_t x0 = 0;
+            uint32_t a0 = 0;
+            while (cA | cB) {
+                hitB = cA == 0;
+                if (!hitB) { L = (uint32_t)__builtin_ctzll(cA); cA &= cA - 1; } else { L = (uint32_t)__builtin_ctzll(cB); cB &= cB - 1; }
+                mp = __builtin_amdgcn_readlane(hitB ? pB : pA, L);
+                mc = __builtin_amdgcn_readlane(hitB ? candB : candA, L);
+                dist = mp - mc;
+                room = mp - anchor; if (mc < room) room = mc;
+                bb0 = 0; bb1 = 1;
+                if (kb <= room) { bb0 = base[mp - kb]; bb1 = base[mc - kb]; }
+                a0 = mp + lane * 8;
+                x0 = 0;
+                if (a0 < end_lim) x0 = ld64_guard(base + a0, rd_end) ^ ld64_guard(base + (a0 - dist), rd_end);
+                if (__builtin_amdgcn_readlane((uint32_t)x0, 0) == 0) { found = true; break; }       // mp + 4 <= end_lim always
             }
-            const uint32_t L = (uint32_t)__builtin_ctzll(hits);
+            if (!found) {                                                           // both steps missed: advance two steps, top up the queue
+                ip = ipC; step = stepC;
+                s0 = s2; s1 = s3; s2 = s4; s3 = s5;
+                s4 = stream(ipN, stepN); ipN += WAVE * stepN; stepN++;
+                s5 = stream(ipN, stepN); ipN += WAVE * stepN; stepN++;
+                continue;
+            }
             // roll back the inserts the greedy parse does not make: lanes beyond the hit (and all of B when A hit)
             if (!hitB) {
                 if (actB) { table[hB] = (uint16_t)eB; tags[hB] = (uint8_t)tB; }
@@ -220,22 +230,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
             } else {
                 if (actB && lane > L) { table[hB] = (uint16_t)eB; tags[hB] = (uint8_t)tB; }
             }
-            uint32_t mp = __builtin_amdgcn_readlane(p_hit, L);
-            uint32_t mc = __builtin_amdgcn_readlane(cand_hit, L);
-            // backward extension over pending literals and forward extension (8 B per lane per round, two rounds): both
-            // start from the probe position, so all their loads are issued together and cost one memory round trip
-            const uint32_t dist = mp - mc;
-            const uint32_t fwd0 = mp + MINMATCH;
-            uint32_t room = mp - anchor; if (mc < room) room = mc;
-            const uint32_t kb = lane + 1;
-            uint8_t bb0 = 0, bb1 = 1;
-            if (kb <= room) { bb0 = base[mp - kb]; bb1 = base[mc - kb]; }
-            uint32_t mlen = MINMATCH;
+            uint32_t mlen = 0;
             {
-                const uint32_t a0 = fwd0 + lane * 8, a1 = a0 + WAVE * 8;
-                uint64_t x0 = 0, x1 = 0;
-                if (a0 < end_lim) x0 = ld64_guard(base + a0, rd_end) ^ ld64_guard(base + (a0 - dist), rd_end);
-                if (a1 < end_lim) x1 = ld64_guard(base + a1, rd_end) ^ ld64_guard(base + (a1 - dist), rd_end);
                 // backward
                 const uint64_t ne = __ballot(!(kb <= room && bb0 == bb1));
                 uint32_t nb = ne ? (uint32_t)__builtin_ctzll(ne) : WAVE;
@@ -251,19 +247,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
                     }
                 }
                 mp -= nb; mc -= nb; mlen += nb;
-                // forward: first two rounds from the loads above
-                uint32_t g0 = 0, g1 = 0;
+                // forward: the first 512 bytes came with the verification; longer matches go on below
+                uint32_t g0 = 0;
                 if (a0 < end_lim) { g0 = x0 ? (uint32_t)(__builtin_ctzll(x0) >> 3) : 8; const uint32_t r = end_lim - a0; if (g0 > r) g0 = r; }
-                if (a1 < end_lim) { g1 = x1 ? (uint32_t)(__builtin_ctzll(x1) >> 3) : 8; const uint32_t r = end_lim - a1; if (g1 > r) g1 = r; }
                 const uint64_t stop0 = __ballot(g0 < 8);
                 bool more = false;
                 if (stop0) { const uint32_t f = (uint32_t)__builtin_ctzll(stop0); mlen += f * 8 + __builtin_amdgcn_readlane(g0, f); }
-                else {
-                    mlen += WAVE * 8;
-                    const uint64_t stop1 = __ballot(g1 < 8);
-                    if (stop1) { const uint32_t f = (uint32_t)__builtin_ctzll(stop1); mlen += f * 8 + __builtin_amdgcn_readlane(g1, f); }
-                    else { mlen += WAVE * 8; more = true; }
-                }
+                else { mlen += WAVE * 8; more = true; }
                 while (more) {                                                      // long matches: keep going, two rounds per trip
                     const uint32_t b0 = mp + mlen + lane * 8, b1 = b0 + WAVE * 8;
                     uint64_t y0 = 0, y1 = 0;

@@ -186,7 +186,8 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     for (int i = 0; i < 4; i++) ev_used[i] = false;
     if (g.n_chunks) {
         tick(0, false);
-        hipLaunchKernelGGL((k_find_matches<W>), dim3((g.n_chunks + W - 1) / W), dim3(64 * W), 0, st, j.d_src, g,
+        constexpr int WF = 1;       // 12 KiB of LDS per wave: one-wave workgroups pack 13 waves into a CU's 160 KiB, four-wave ones 12
+        hipLaunchKernelGGL((k_find_matches<WF>), dim3((g.n_chunks + WF - 1) / WF), dim3(64 * WF), 0, st, j.d_src, g,
                            (ChunkInfo*)info.p, (uint64_t*)recs.p);
         tick(0, true);
     }
