@@ -293,17 +293,18 @@ __device__ __forceinline__ void fz_copier(FzShared& sh, const uint8_t* __restric
             // stalled everything behind it for a memory round trip (~10 % of the matches at six in flight).
             constexpr int NJ = FZ_MATCH_SET;
             const uint32_t mdm = vdst + vlen;                                   // my match's destination, source = mdm - voff
-            const uint32_t ms0 = mdm - voff, ms1 = ms0 + vml;                   // (wraps for a source in a linked frame's history: no dependency)
+            // signed: a source may start in the history in front of a linked block (negative) and end inside the block
+            const int32_t ms0 = (int32_t)mdm - (int32_t)voff, ms1 = ms0 + (int32_t)vml;
             const bool has = lane < count && vml != 0;
             const uint64_t fastmask = __ballot(has && vml >= 16 && vml <= 1024 && voff >= vml);   // one non-overlapping round
             uint32_t dep_lo = 0, dep_hi = 0;
             for (uint32_t k = 0; k < count && k < 32; k++) {
                 const uint32_t dk = __builtin_amdgcn_readlane(mdm, k), mk = __builtin_amdgcn_readlane(vml, k);
-                dep_lo |= (k < lane && mk != 0 && ms0 < dk + mk && ms1 > dk) ? (1u << k) : 0u;
+                dep_lo |= (k < lane && mk != 0 && ms0 < (int32_t)(dk + mk) && ms1 > (int32_t)dk) ? (1u << k) : 0u;
             }
             for (uint32_t k = 32; k < count; k++) {
                 const uint32_t dk = __builtin_amdgcn_readlane(mdm, k), mk = __builtin_amdgcn_readlane(vml, k);
-                dep_hi |= (k < lane && mk != 0 && ms0 < dk + mk && ms1 > dk) ? (1u << (k - 32)) : 0u;
+                dep_hi |= (k < lane && mk != 0 && ms0 < (int32_t)(dk + mk) && ms1 > (int32_t)dk) ? (1u << (k - 32)) : 0u;
             }
             uint64_t todo = __ballot(has), unstored = todo;
             auto ready = [&]() -> uint64_t {

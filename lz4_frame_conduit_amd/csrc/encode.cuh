@@ -223,12 +223,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
                 s5 = stream(ipN, stepN); ipN += WAVE * stepN; stepN++;
                 continue;
             }
-            // roll back the inserts the greedy parse does not make: lanes beyond the hit (and all of B when A hit)
+            // roll back the inserts the greedy parse does not make: lanes beyond the hit (and all of B when A hit).  Several
+            // lanes of a step can share a table slot (periodic data): a lane beyond the hit restoring "its" old value would
+            // also wipe the insert of a lane up to the hit, so those are written again afterwards.
             if (!hitB) {
                 if (actB) { table[hB] = (uint16_t)eB; tags[hB] = (uint8_t)tB; }
                 if (actA && lane > L) { table[hA] = (uint16_t)eA; tags[hA] = (uint8_t)tA; }
+                if (actA && lane <= L) { table[hA] = (uint16_t)pA; tags[hA] = (uint8_t)tgA; }
             } else {
                 if (actB && lane > L) { table[hB] = (uint16_t)eB; tags[hB] = (uint8_t)tB; }
+                if (actB && lane <= L) { table[hB] = (uint16_t)pB; tags[hB] = (uint8_t)tgB; }
             }
             uint32_t mlen = 0;
             {

@@ -98,3 +98,36 @@ def mutate(frame: bytes, pos: int, xor: int = 0xFF) -> bytes:
     b = bytearray(frame)
     b[pos] ^= xor
     return bytes(b)
+
+
+def structured(n: int, seed: int) -> bytes:
+    """Test-input generator with the sequence shapes an LZ4 codec has to survive: literal runs and matches of every
+    length class (below 16, a few hundred, beyond 1 KiB, tens of KiB), self-overlapping matches (period 1..63 and
+    64..1023), far and near offsets, and matches that run into the end of the buffer.  Deterministic in (n, seed)."""
+    rng = np.random.default_rng(seed)
+    out = bytearray()
+    alphabets = [256, 256, 16, 4, 2]
+    while len(out) < n:
+        kind = int(rng.integers(0, 8))
+        if kind <= 1 or len(out) < 8:                                   # literals
+            ln = int(rng.choice([1, 3, 14, 15, 16, 40, 270, 271, 600, 5000]))
+            out += rng.integers(0, int(rng.choice(alphabets)), ln, dtype=np.uint8).tobytes()
+        elif kind == 2:                                                 # run / short period (overlapping match)
+            period = int(rng.choice([1, 2, 3, 7, 15, 16, 17, 33, 63]))
+            ln = int(rng.choice([5, 19, 64, 300, 1025, 4000, 70000]))
+            pat = bytes(out[-period:]) if len(out) >= period else b"\x00" * period
+            out += (pat * (ln // period + 1))[:ln]
+        elif kind == 3:                                                 # medium period (overlap, 64 <= period < 1024)
+            period = int(rng.integers(64, 1024))
+            if len(out) >= period:
+                ln = int(rng.integers(period, 6 * period))
+                pat = bytes(out[-period:])
+                out += (pat * (ln // period + 1))[:ln]
+        else:                                                           # copy from earlier: near, far, beyond the 64 KiB window
+            back = int(rng.choice([4, 17, 100, 1000, 5000, 30000, 65535, 65536, 200000]))
+            ln = int(rng.choice([4, 5, 8, 15, 18, 19, 20, 100, 273, 274, 512, 1023, 1024, 1025, 3000, 20000]))
+            if back <= len(out):
+                start = len(out) - back
+                ln = min(ln, back)
+                out += out[start:start + ln]
+    return bytes(out[:n])
