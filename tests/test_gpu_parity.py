@@ -235,10 +235,12 @@ def test_device_resident_path_and_block_table(L):
     walk kernel rebuilds the same table from the frame bytes."""
     import torch
     from lz4_frame_conduit_amd.device import Engine
-    data = datagen.synth50(16 << 20, 77)
-    src = torch.from_numpy(data).cuda()
     eng = Engine(0)
-    for kw in (dict(bsid=7, indep=1, bck=1), dict(bsid=4, indep=1), dict(bsid=4, indep=0)):
+    shapes = [(datagen.synth50(16 << 20, 77), kw) for kw in (dict(bsid=7, indep=1, bck=1), dict(bsid=4, indep=1), dict(bsid=4, indep=0))]
+    shapes += [(np.frombuffer(datagen.structured(9 << 20, 2000 + i), dtype=np.uint8).copy(), kw)
+               for i, kw in enumerate((dict(bsid=7, indep=1), dict(bsid=7, indep=0, bck=1), dict(bsid=5, indep=0), dict(bsid=6, indep=1)))]
+    for data, kw in shapes:
+        src = torch.from_numpy(data).cuda()
         p = prefs_of(kw)
         cap = eng.frame_bound(src.numel(), p)
         frame = torch.empty(cap, dtype=torch.uint8, device="cuda")
@@ -364,13 +366,13 @@ def test_batched_decoder_walks_whole_streams(L, golden, named_inputs):
 
 # ------------------------------------------------------------------------------------------------
 # Sequence-shape fuzz: inputs built to hit every length class and overlap case of the copy paths (datagen.structured),
-# both directions, every block size, linked and independent, against the oracle (bit-exact with liblz4).
+# both directions, every block size, linked and independent, against the oracle (bit-exact with liblz4): 72 cases.
 def test_structured_inputs_both_directions(L):
     sizes = [70000, 300000, 1 << 20, (4 << 20) + 12345, 9 << 20]
     combos = [dict(bsid=4, indep=1), dict(bsid=4, indep=0), dict(bsid=5, indep=1, bck=1), dict(bsid=6, indep=0, cck=1), dict(bsid=7, indep=1), dict(bsid=7, indep=0)]
     n_cases = 0
     worst = (0.0, -1, "")
-    for seed in range(6):
+    for seed in range(12):
         data = datagen.structured(sizes[seed % len(sizes)], 1000 + seed)
         for kw in combos:
             ref = oracle.conduit_compress(data, oracle.mkprefs(**kw))
@@ -381,7 +383,7 @@ def test_structured_inputs_both_directions(L):
             assert gpu_decompress_frame(L, frame, len(data) + 8)[0] == data, (seed, kw, "encode/gpu")
             worst = max(worst, (len(frame) / len(ref), seed, str(kw)))
             n_cases += 1
-    assert n_cases == 36
+    assert n_cases == 72
     # these inputs are built to stress the copy paths, not to look like data: tiny alphabets and 4-byte matches favour
     # liblz4's position-by-position search over 64 probes per step.  The ratio bar of the parity configs (RATIO_TOL) is
     # checked on their inputs above; here only a sanity bound.
