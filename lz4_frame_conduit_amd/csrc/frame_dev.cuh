@@ -251,9 +251,22 @@ __global__ __launch_bounds__(64) void k_finish_decode(uint8_t* dst, BlockOut* __
         if (lane == 0) { res->status = (bad_kind == (uint32_t)-2) ? ST_DSTSMALL : ST_GENERIC; res->first_bad_block = first_bad; }
         return;
     }
+    // usual case, checked 64 blocks per step: every block already sits where its predecessors end (all blocks but
+    // the last decoded to full size), so nothing has to move and the total is a sum
     uint64_t out = 0;
-    if (!linked) {
-        for (uint32_t b = 0; b < n; b++) {          // uniform, serial: n is small and this is a rare path
+    bool in_place = true;
+    for (uint32_t b0 = 0; b0 < n; b0 += WAVE) {
+        const uint32_t b = b0 + lane;
+        const uint32_t sz = b < n ? table[b].dst_size : 0u;
+        const uint64_t at = b < n ? table[b].dst_off : 0ull;
+        uint64_t incl = sz;
+        for (uint32_t d = 1; d < WAVE; d <<= 1) { const uint64_t t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+        if (!linked && __ballot(b < n && at != out + incl - sz)) { in_place = false; break; }
+        out += __shfl(incl, WAVE - 1);
+    }
+    if (!in_place) {
+        out = 0;
+        for (uint32_t b = 0; b < n; b++) {          // uniform, serial: a rare path (a non-final block of an independent frame decoded short)
             const uint64_t at = table[b].dst_off; const uint32_t sz = table[b].dst_size;
             if (at != out) {
                 for (uint32_t o = 0; o < sz; o += 1024) {            // forward move to a lower address
@@ -269,8 +282,6 @@ __global__ __launch_bounds__(64) void k_finish_decode(uint8_t* dst, BlockOut* __
             }
             out += sz;
         }
-    } else {
-        for (uint32_t b = 0; b < n; b++) out += table[b].dst_size;
     }
     if (lane == 0) {
         const uint64_t declared = res->size;
