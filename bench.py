@@ -44,7 +44,7 @@ def pmc_traffic(kernel: str, n_bytes: int, block_size: int):
             prof = json.load(f)
         if n_bytes != (4 << 30) or block_size != (4 << 20):
             return None
-        names = {"find_matches": "k_find_matches<1>", "emit": "k_emit<4>", "decode": "k_decode_blocks_fused"}
+        names = {"find_matches": "k_find_matches<1>", "emit": "k_emit<4>", "decode": "k_decode_blocks_fused<lz4f::FzCfg<8> >"}
         return int(prof["kernels"][names[kernel]]["hbm_bytes_corrected"])
     except Exception:
         return None

@@ -23,15 +23,19 @@
 
 namespace lz4f {
 
-constexpr int      FZ_WAVES = 8;
-constexpr uint32_t FZ_STAGE = 8192;
+// Two shapes of the same workgroup.  Big blocks (one block per workgroup slot of the machine): 8 waves, 4 workgroups
+// per CU.  Blocks of 1 MiB and less (more blocks than slots): 4 waves and a third of the LDS, 8 workgroups per CU -
+// three copiers keep up with one parser, and twice as many blocks are in flight.
+template <int W> struct FzCfg;
+template <> struct FzCfg<8> { static constexpr int WAVES = 8; static constexpr uint32_t STAGE = 8192, RING = 8, LDS_BUDGET = 40960; };
+template <> struct FzCfg<4> { static constexpr int WAVES = 4; static constexpr uint32_t STAGE = 2048, RING = 4, LDS_BUDGET = 20480; };
 constexpr uint32_t FZ_OVER = 576;                // >= the parser's 520-byte register window + 8
-constexpr uint32_t FZ_RING = 8;                 // slots of 64 descriptors
 constexpr int      FZ_MATCH_SET = 3;            // match copies per register set (two sets in flight)
 
+template <class C>
 struct alignas(16) FzShared {
-    uint4    ring[FZ_RING][64];
-    uint8_t  stage[2][FZ_STAGE + FZ_OVER];
+    uint4    ring[C::RING][64];
+    uint8_t  stage[2][C::STAGE + FZ_OVER];
     uint32_t produced;                          // slots the parser has published
     uint32_t total_slots;                       // valid once `finished` is set
     uint32_t last_count;                        // descriptors in the last slot
@@ -41,17 +45,18 @@ struct alignas(16) FzShared {
     uint32_t out_size;
     uint32_t pad;
 };
-static_assert(sizeof(FzShared) <= 40960, "4 workgroups per CU");
+static_assert(sizeof(FzShared<FzCfg<8>>) <= FzCfg<8>::LDS_BUDGET && sizeof(FzShared<FzCfg<4>>) <= FzCfg<4>::LDS_BUDGET, "workgroups per CU");
 
 __device__ __forceinline__ uint32_t lds_peek(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 __device__ __forceinline__ void lds_poke(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
 
+template <class C>
 __device__ __forceinline__ void fz_stage_issue(uint8_t* slot, const uint8_t* __restrict__ in, uint32_t csize, uint32_t s)
 {
     const uint32_t lane = lane_id();
-    const uint32_t base = s * FZ_STAGE;
+    const uint32_t base = s * C::STAGE;
     if (base >= csize) return;
-    const uint32_t end = (base + FZ_STAGE + FZ_OVER < csize) ? base + FZ_STAGE + FZ_OVER : csize;
+    const uint32_t end = (base + C::STAGE + FZ_OVER < csize) ? base + C::STAGE + FZ_OVER : csize;
     const uint32_t span = end - base;
     for (uint32_t piece = 0; piece < span; piece += 1024) {
         const uint32_t o = piece + lane * 16;
@@ -62,7 +67,8 @@ __device__ __forceinline__ void fz_stage_issue(uint8_t* slot, const uint8_t* __r
 }
 
 // ---------------- parser wave ----------------
-__device__ __forceinline__ void fz_parser(FzShared& sh, const uint8_t* __restrict__ in, uint32_t csize, uint32_t cap, uint64_t hist,
+template <class C>
+__device__ __forceinline__ void fz_parser(FzShared<C>& sh, const uint8_t* __restrict__ in, uint32_t csize, uint32_t cap, uint64_t hist,
                                           unsigned long long* prof)
 {
     const unsigned long long t_begin = clock64(); unsigned long long t_ring = 0;
@@ -74,16 +80,16 @@ __device__ __forceinline__ void fz_parser(FzShared& sh, const uint8_t* __restric
     uint32_t d0 = 0, d1 = 0, d2 = 0, d3 = 0;
 
     if (csize == 0) status = 1;
-    else fz_stage_issue(stages, in, csize, 0);
+    else fz_stage_issue<C>(stages, in, csize, 0);
     auto need = [&](uint32_t qq) {
-        const int32_t s = (int32_t)(qq / FZ_STAGE);
+        const int32_t s = (int32_t)(qq / C::STAGE);
         if (s == cur) return;
         // next stage in sequence: its DMA is in flight -> wait, then start the one after.  A jump further ahead (a very
         // long literal run) first has to start its own stage.
 #pragma unroll 1
         for (int32_t it = (s == cur + 1) ? 1 : 0; it < 2; it++) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            fz_stage_issue(stages + (uint32_t)((s + it) & 1) * (FZ_STAGE + FZ_OVER), in, csize, (uint32_t)(s + it));
+            fz_stage_issue<C>(stages + (uint32_t)((s + it) & 1) * (C::STAGE + FZ_OVER), in, csize, (uint32_t)(s + it));
         }
         cur = s;
     };
@@ -95,9 +101,9 @@ __device__ __forceinline__ void fz_parser(FzShared& sh, const uint8_t* __restric
     uint32_t wb = 0xFFFFFC00u;                       // nothing loaded yet: every position misses
     auto reload = [&](uint32_t qq) {
         need(qq);
-        const uint32_t s = qq / FZ_STAGE;
-        const uint32_t o = (qq - s * FZ_STAGE) & ~7u;
-        const uint32_t addr = (uint32_t)(uintptr_t)(lptr_t)(stages + (s & 1) * (FZ_STAGE + FZ_OVER)) + o + 8u * lane;
+        const uint32_t s = qq / C::STAGE;
+        const uint32_t o = (qq - s * C::STAGE) & ~7u;
+        const uint32_t addr = (uint32_t)(uintptr_t)(lptr_t)(stages + (s & 1) * (C::STAGE + FZ_OVER)) + o + 8u * lane;
         // inline asm: keeps hipcc from draining vmcnt (the pending stage prefetch) before this LDS read
         asm volatile("ds_read2_b64 %0, %1 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(win) : "v"(addr) : "memory");
         wb = qq & ~7u;
@@ -123,9 +129,9 @@ __device__ __forceinline__ void fz_parser(FzShared& sh, const uint8_t* __restric
     // publish the gathered descriptors as ring slot number `slot_idx`
     auto publish = [&](uint32_t slot_idx) {
         const unsigned long long tr = clock64();
-        while (slot_idx >= lds_peek(&sh.match_done) + FZ_RING) __builtin_amdgcn_s_sleep(8);    // ring full: wait for the oldest slot
+        while (slot_idx >= lds_peek(&sh.match_done) + C::RING) __builtin_amdgcn_s_sleep(8);    // ring full: wait for the oldest slot
         t_ring += clock64() - tr;
-        sh.ring[slot_idx % FZ_RING][lane] = uint4{d0, d1, d2, d3};
+        sh.ring[slot_idx % C::RING][lane] = uint4{d0, d1, d2, d3};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         lds_poke(&sh.produced, slot_idx + 1);
     };
@@ -201,8 +207,8 @@ __device__ __forceinline__ void fz_parser(FzShared& sh, const uint8_t* __restric
     // performed in order; a copier reads `produced` first, then `finished`).
     const uint32_t full = nseq >> 6, part = (status == 0) ? (nseq & 63) : 0;
     if (part) {
-        while (full >= lds_peek(&sh.match_done) + FZ_RING) __builtin_amdgcn_s_sleep(8);
-        sh.ring[full % FZ_RING][lane] = uint4{d0, d1, d2, d3};
+        while (full >= lds_peek(&sh.match_done) + C::RING) __builtin_amdgcn_s_sleep(8);
+        sh.ring[full % C::RING][lane] = uint4{d0, d1, d2, d3};
     }
     sh.total_slots = status ? lds_peek(&sh.produced) : full + (part ? 1u : 0u);       // (all lanes store the same values)
     sh.last_count = part ? part : 64;
@@ -215,13 +221,14 @@ __device__ __forceinline__ void fz_parser(FzShared& sh, const uint8_t* __restric
 }
 
 // ---------------- copier waves ----------------
-__device__ __forceinline__ void fz_copier(FzShared& sh, const uint8_t* __restrict__ in, uint8_t* out, uint32_t cw /* 0..6 */,
+template <class C>
+__device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __restrict__ in, uint8_t* out, uint32_t cw /* 0..6 */,
                                           const uint8_t* safe /* 16 readable bytes */, unsigned long long* prof)
 {
     const uint32_t lane = lane_id();
     unsigned long long t_wait_p = 0, t_lit = 0, t_wait_m = 0, t_match = 0, n_slots = 0;
     auto dump = [&]() { if (prof && blockIdx.x == 0 && lane == 0) { unsigned long long* o = prof + 8 * (cw + 1); o[0] = t_wait_p; o[1] = t_lit; o[2] = t_wait_m; o[3] = t_match; o[4] = n_slots; } };
-    for (uint32_t slot = cw;; slot += FZ_WAVES - 1) {
+    for (uint32_t slot = cw;; slot += C::WAVES - 1) {
         // wait for the slot (or for the end of the block)
         const unsigned long long c0 = clock64();
         for (;;) {
@@ -231,7 +238,7 @@ __device__ __forceinline__ void fz_copier(FzShared& sh, const uint8_t* __restric
         }
         const unsigned long long c1 = clock64(); t_wait_p += c1 - c0; n_slots++;
         __builtin_amdgcn_s_setprio(1);                                       // copying beats polling
-        const uint4 d = sh.ring[slot % FZ_RING][lane];
+        const uint4 d = sh.ring[slot % C::RING][lane];
         // descriptors in this slot: 64, except a partial last slot -- which is published only after `finished`
         uint32_t count = 64;
         if (lds_peek(&sh.finished) && slot + 1 == lds_peek(&sh.total_slots)) count = lds_peek(&sh.last_count);
@@ -368,7 +375,8 @@ __device__ __forceinline__ void fz_copier(FzShared& sh, const uint8_t* __restric
 }
 
 // Decode one compressed block with the whole workgroup; returns decoded size or -1 (same value in all threads).
-__device__ __forceinline__ int32_t fz_decode_block(FzShared& sh, const uint8_t* __restrict__ in, uint32_t csize, uint8_t* out, uint32_t cap, uint64_t hist,
+template <class C>
+__device__ __forceinline__ int32_t fz_decode_block(FzShared<C>& sh, const uint8_t* __restrict__ in, uint32_t csize, uint8_t* out, uint32_t cap, uint64_t hist,
                                                    const uint8_t* safe, unsigned long long* prof)
 {
     const uint32_t wave = uni(threadIdx.x >> 6);
@@ -377,22 +385,23 @@ __device__ __forceinline__ int32_t fz_decode_block(FzShared& sh, const uint8_t* 
     __syncthreads();
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);                                   // the serial chain: win issue arbitration against the 7 copier waves of this SIMD
-        fz_parser(sh, in, csize, cap, hist, prof);
+        fz_parser<C>(sh, in, csize, cap, hist, prof);
         __builtin_amdgcn_s_setprio(0);
     }
-    else fz_copier(sh, in, out, wave - 1, safe, prof);
+    else fz_copier<C>(sh, in, out, wave - 1, safe, prof);
     __syncthreads();                                                     // all copies of this block are issued and complete
     const int32_t st = (int32_t)uni((uint32_t)sh.status);
     const uint32_t osz = uni(sh.out_size);
     return st < 0 ? -1 : (int32_t)osz;
 }
 
-__global__ __launch_bounds__(64 * FZ_WAVES, 8) void k_decode_blocks_fused(const uint8_t* __restrict__ frame, uint8_t* dst, uint64_t dst_cap,
+template <class C>
+__global__ __launch_bounds__(64 * C::WAVES, 8) void k_decode_blocks_fused(const uint8_t* __restrict__ frame, uint8_t* dst, uint64_t dst_cap,
                                                                           BlockOut* __restrict__ table, const ResultRec* __restrict__ res,
                                                                           uint32_t n_max, uint32_t linked, uint32_t block_size, uint64_t hist0,
                                                                           unsigned long long* prof)
 {
-    __shared__ FzShared sh;
+    __shared__ FzShared<C> sh;
     if (res->status != ST_OK) return;
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
     const uint32_t tid = threadIdx.x;
@@ -409,17 +418,17 @@ __global__ __launch_bounds__(64 * FZ_WAVES, 8) void k_decode_blocks_fused(const 
         if (e.word >> 31) {                                              // stored block: all waves copy a slice
             if (csz > room) got = -2;
             else {
-                const uint32_t per = (((csz + FZ_WAVES - 1) / FZ_WAVES) + 15) & ~15u;
+                const uint32_t per = (((csz + C::WAVES - 1) / C::WAVES) + 15) & ~15u;
                 const uint32_t a = (tid >> 6) * per;
                 if (a < csz) wave_copy_disjoint(dst + at + a, frame + e.src_off + a, (csz - a < per) ? csz - a : per);
                 got = (int32_t)csz;
             }
         } else {
-            got = fz_decode_block(sh, frame + e.src_off, csz, dst + at, room, linked ? out + hist0 : 0, frame, prof);
+            got = fz_decode_block<C>(sh, frame + e.src_off, csz, dst + at, room, linked ? out + hist0 : 0, frame, prof);
         }
         if (tid == 0) { table[b].dst_off = at; table[b].dst_size = (uint32_t)got; }
         if (got < 0) {
-            if (linked) for (uint32_t k = b + 1 + tid; k < n; k += 64 * FZ_WAVES) table[k].dst_size = 0;
+            if (linked) for (uint32_t k = b + 1 + tid; k < n; k += 64 * C::WAVES) table[k].dst_size = 0;
             break;
         }
         out += (uint32_t)got;

@@ -253,9 +253,15 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         char mode = (j.linked || j.block_size >= (256u << 10)) ? 'f' : '1';
         if (const char* dv = getenv("LZ4F_MI355X_DECODE")) mode = dv[0];
         if (mode == 'f') {
-            hipLaunchKernelGGL(k_decode_blocks_fused, dim3(j.linked ? 1u : n_max), dim3(64 * FZ_WAVES), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
-                               (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, j.hist0,
-                               (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr));
+            unsigned long long* prof = (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr);
+            // more blocks than the machine has 8-wave workgroup slots: the 4-wave shape keeps twice as many in flight
+            const bool small = !j.linked && j.block_size <= (1u << 20);
+            if (small)
+                hipLaunchKernelGGL(k_decode_blocks_fused<FzCfg<4>>, dim3(n_max), dim3(64 * 4), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
+                                   (const ResultRec*)d_res, n_max, 0u, j.block_size, j.hist0, prof);
+            else
+                hipLaunchKernelGGL(k_decode_blocks_fused<FzCfg<8>>, dim3(j.linked ? 1u : n_max), dim3(64 * 8), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
+                                   (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, j.hist0, prof);
         } else if (mode == '2') {
             const size_t per_block = (size_t)j.block_size / 4 + 2;
             if (desc.ensure((size_t)n_max * per_block * sizeof(SeqDesc)) || seqcnt.ensure((size_t)n_max * 8 + 64)) return make_err(LZ4F_ERROR_allocation_failed);
