@@ -334,7 +334,9 @@ size_t lz4f_mi355x_engine::run_decode_slab(const uint8_t* frame_part, size_t par
     const bool linked = ph.info.blockMode == LZ4F_blockLinked;
     if (!linked) hist_len = 0;
     const size_t nb = entries.size();
-    const size_t out_room = std::min(dst_room, nb * ph.max_block);
+    // the device buffer always has room for every block at full size: blocks are decoded at provisional positions and
+    // compacted when some are short (frames written with LZ4F_flush); only what is actually produced must fit `dst`
+    const size_t out_room = nb * ph.max_block;
     const size_t tbytes = nb * sizeof(BlockOut);
     if (h_in.ensure(part_len + tbytes + hist_len + 64) || d_in.ensure(part_len + 64) || d_out.ensure(hist_len + out_room + 64) ||
         h_out.ensure(out_room + sizeof(ResultRec) + 64) || res.ensure(sizeof(ResultRec)) || table.ensure((nb + 1) * sizeof(BlockOut)))
@@ -401,10 +403,9 @@ size_t lz4f_mi355x_engine::decompress_frame_host(const uint8_t* s, size_t n, con
             if (csz > ph.max_block) return make_err(LZ4F_ERROR_maxBlockSize_invalid);
             if (n - pos - 4 < csz + crc) return make_err(LZ4F_ERROR_frameHeader_incomplete);
             if (!entries.empty() && ((pos - slab_src) + 4 + csz + crc > SLAB_SRC || prov + ph.max_block > SLAB_DST)) break;
-            if (out + prov >= cap && !(csz == 0)) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
             lz4f_mi355x_block e;
             e.src_off = pos + 4 - slab_src; e.dst_off = prov; e.word = w;
-            e.dst_size = (uint32_t)std::min(ph.max_block, cap - out - prov);
+            e.dst_size = (uint32_t)ph.max_block;
             entries.push_back(e);
             pos += 4 + csz + crc; prov += ph.max_block;
         }

@@ -389,3 +389,54 @@ def test_structured_inputs_both_directions(L):
     # checked on their inputs above; here only a sanity bound.
     print("worst size ratio vs liblz4 on structured inputs: %.3f (seed %d, %s)" % worst)
     assert worst[0] <= 1.25, worst
+
+
+# ------------------------------------------------------------------------------------------------
+# Streaming compress API under arbitrary call patterns: random slice sizes (0 .. several blocks), LZ4F_flush at random
+# points, autoFlush on/off, every framing.  Each call must stay within LZ4F_compressBound of its slice, and the
+# concatenated output must be a frame the oracle (= liblz4's decoder) and the GPU decode to the input.
+def test_streaming_compress_random_call_patterns(L, named_inputs):
+    rng = np.random.default_rng(4242)
+    data_all = datagen.structured(3 << 20, 3001) + named_inputs["text512k"]
+    framings = [dict(bsid=4, indep=0), dict(bsid=4, indep=1, bck=1), dict(bsid=5, indep=0, cck=1), dict(bsid=6, indep=1), dict(bsid=7, indep=0), dict(bsid=7, indep=1, cck=1, bck=1)]
+    for trial in range(12):
+        kw = dict(framings[trial % len(framings)])
+        auto = int(trial % 3 == 1)
+        n = int(rng.integers(1, len(data_all)))
+        start = int(rng.integers(0, len(data_all) - n + 1))
+        data = data_all[start:start + n]
+        p = prefs_of(kw); p.autoFlush = auto
+        c = ctypes.c_void_p(); assert L.LZ4F_createCompressionContext(ctypes.byref(c), 100) == 0
+        out = []
+        hdr = ctypes.create_string_buffer(32)
+        r = L.LZ4F_compressBegin(c, hdr, 32, ctypes.byref(p)); assert not L.LZ4F_isError(r)
+        out.append(hdr.raw[:r])
+        pos = 0
+        while pos < n:
+            kind = int(rng.integers(0, 10))
+            if kind == 0:
+                k = 0
+            elif kind <= 5:
+                k = int(rng.integers(1, 70000))
+            else:
+                k = int(rng.integers(1, 3 << 20))
+            k = min(k, n - pos)
+            bound = L.LZ4F_compressBound(k, ctypes.byref(p))
+            dst = ctypes.create_string_buffer(max(bound, 1))
+            r = L.LZ4F_compressUpdate(c, dst, bound, data[pos:pos + k], k, None)
+            assert not L.LZ4F_isError(r), (trial, L.LZ4F_getErrorName(r), L.lz4f_mi355x_last_error())
+            assert r <= bound
+            out.append(dst.raw[:r]); pos += k
+            if int(rng.integers(0, 6)) == 0:
+                fb = L.LZ4F_compressBound(0, ctypes.byref(p)); fd = ctypes.create_string_buffer(fb)
+                r = L.LZ4F_flush(c, fd, fb, None); assert not L.LZ4F_isError(r) and r <= fb
+                out.append(fd.raw[:r])
+        eb = L.LZ4F_compressBound(0, ctypes.byref(p)); ed = ctypes.create_string_buffer(eb)
+        r = L.LZ4F_compressEnd(c, ed, eb, None); assert not L.LZ4F_isError(r) and r <= eb
+        out.append(ed.raw[:r])
+        L.LZ4F_freeCompressionContext(c)
+        frame = b"".join(out)
+        got, used = oracle.decompress_frame(frame, n + 64)
+        assert used == len(frame) and got == data, (trial, kw, auto)
+        got2, used2 = gpu_decompress_frame(L, frame, n + 8)
+        assert used2 == len(frame) and got2 == data, (trial, kw, auto)
