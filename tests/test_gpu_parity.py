@@ -440,3 +440,46 @@ def test_streaming_compress_random_call_patterns(L, named_inputs):
         assert used == len(frame) and got == data, (trial, kw, auto)
         got2, used2 = gpu_decompress_frame(L, frame, n + 8)
         assert used2 == len(frame) and got2 == data, (trial, kw, auto)
+
+
+# ------------------------------------------------------------------------------------------------
+# Streaming decompress API under arbitrary call patterns: random source slice sizes and destination capacities (down
+# to 1 byte), over frames with short (flushed) blocks, stored blocks, checksums, skippable and concatenated frames.
+def test_streaming_decompress_random_call_patterns(L, named_inputs):
+    rng = np.random.default_rng(777)
+    text = named_inputs["text512k"]; rnd = named_inputs["random10m"][:200000]; st = datagen.structured(1 << 20, 3100)
+    skip = bytes.fromhex("5a2a4d18") + (7).to_bytes(4, "little") + b"skipme!"
+    def flushed(data, kw, slice_):                      # oracle frame with autoFlush: one (short) block per slice
+        return oracle.conduit_compress(data, oracle.mkprefs(autoflush=1, **kw), slice_)
+    streams = [
+        (oracle.conduit_compress(st, oracle.mkprefs(bsid=4, indep=0, cck=1)), st),
+        (oracle.conduit_compress(text, oracle.mkprefs(bsid=7, indep=1, bck=1, cck=1)), text),
+        (flushed(text, dict(bsid=5, indep=0, cck=1), 10000), text),
+        (flushed(st, dict(bsid=4, indep=1, bck=1), 50000), st),
+        (oracle.conduit_compress(rnd, oracle.mkprefs(bsid=4, indep=1, csize=len(rnd))), rnd),
+        (skip + oracle.conduit_compress(text, oracle.mkprefs(bsid=6, indep=1)) + skip + oracle.conduit_compress(rnd, oracle.mkprefs(bsid=4, indep=0)), text + rnd),
+    ]
+    for si, (stream, want) in enumerate(streams):
+        for trial in range(2):
+            d = ctypes.c_void_p(); assert L.LZ4F_createDecompressionContext(ctypes.byref(d), 100) == 0
+            out = bytearray(); pos = 0; hint = 1; calls = 0
+            small = trial == 1
+            while pos < len(stream):
+                k = int(rng.integers(1, 300 if small else 120000)); k = min(k, len(stream) - pos)
+                cap = int(rng.integers(1, 500 if small else 300000))
+                dst = ctypes.create_string_buffer(cap); ds = ctypes.c_size_t(cap); ss = ctypes.c_size_t(k)
+                hint = L.LZ4F_decompress(d, dst, ctypes.byref(ds), stream[pos:pos + k], ctypes.byref(ss), None)
+                assert not L.LZ4F_isError(hint), (si, trial, L.LZ4F_getErrorName(hint), L.lz4f_mi355x_last_error())
+                assert ss.value <= k and ds.value <= cap
+                out += dst.raw[:ds.value]; pos += ss.value; calls += 1
+                assert calls < 2_000_000
+            # drain what the context still holds (nothing left to feed)
+            while hint != 0:
+                dst = ctypes.create_string_buffer(65536); ds = ctypes.c_size_t(65536); ss = ctypes.c_size_t(0)
+                hint = L.LZ4F_decompress(d, dst, ctypes.byref(ds), b"", ctypes.byref(ss), None)
+                assert not L.LZ4F_isError(hint)
+                if ds.value == 0: break
+                out += dst.raw[:ds.value]
+            L.LZ4F_freeDecompressionContext(d)
+            assert hint == 0, (si, trial)
+            assert bytes(out) == want, (si, trial, len(out), len(want))
