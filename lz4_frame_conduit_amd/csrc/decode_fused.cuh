@@ -399,10 +399,11 @@ template <class C>
 __global__ __launch_bounds__(64 * C::WAVES, 8) void k_decode_blocks_fused(const uint8_t* __restrict__ frame, uint8_t* dst, uint64_t dst_cap,
                                                                           BlockOut* __restrict__ table, const ResultRec* __restrict__ res,
                                                                           uint32_t n_max, uint32_t linked, uint32_t block_size, uint64_t hist0,
-                                                                          unsigned long long* prof)
+                                                                          unsigned long long* prof, const uint32_t* __restrict__ only_if)
 {
     __shared__ FzShared<C> sh;
     if (res->status != ST_OK) return;
+    if (only_if && *only_if == 0) return;                                // (fallback launch behind decode_linked.cuh: nothing to do)
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
     const uint32_t tid = threadIdx.x;
     if (linked && blockIdx.x != 0) return;

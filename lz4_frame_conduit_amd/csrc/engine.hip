@@ -256,12 +256,27 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             unsigned long long* prof = (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr);
             // more blocks than the machine has 8-wave workgroup slots: the 4-wave shape keeps twice as many in flight
             const bool small = !j.linked && j.block_size <= (1u << 20);
+            // a linked frame is one chain: one workgroup with the 64 KiB window in LDS; frames with short (flushed) blocks
+            // set the flag and are decoded by the generic kernel launched right behind (it returns at once otherwise)
+            const bool windowed = j.linked && j.dst_cap < 0xFFF00000ull && !getenv("LZ4F_MI355X_NO_WINDOW");
+            const uint32_t* only_if = nullptr;
+            if (windowed) {
+                if (seqcnt.ensure(256)) return make_err(LZ4F_ERROR_allocation_failed);
+                hipLaunchKernelGGL(k_decode_linked, dim3(1), dim3(64 * LK_WAVES), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
+                                   (const ResultRec*)d_res, n_max, j.block_size, j.hist0, (uint32_t*)seqcnt.p);
+                only_if = (const uint32_t*)seqcnt.p;
+                if (getenv("LZ4F_MI355X_PROF")) {                              // developer aid: why the windowed kernel stopped, if it did
+                    uint32_t dbg[3] = {0, 0, 0};
+                    if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(dbg, seqcnt.p, 12, hipMemcpyDeviceToHost) == hipSuccess)
+                        fprintf(stderr, "k_decode_linked: fallback %u why %u block %u\n", dbg[0], dbg[1], dbg[2]);
+                }
+            }
             if (small)
                 hipLaunchKernelGGL(k_decode_blocks_fused<FzCfg<4>>, dim3(n_max), dim3(64 * 4), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
-                                   (const ResultRec*)d_res, n_max, 0u, j.block_size, j.hist0, prof);
+                                   (const ResultRec*)d_res, n_max, 0u, j.block_size, j.hist0, prof, only_if);
             else
                 hipLaunchKernelGGL(k_decode_blocks_fused<FzCfg<8>>, dim3(j.linked ? 1u : n_max), dim3(64 * 8), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
-                                   (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, j.hist0, prof);
+                                   (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, j.hist0, prof, only_if);
         } else if (mode == '2') {
             const size_t per_block = (size_t)j.block_size / 4 + 2;
             if (desc.ensure((size_t)n_max * per_block * sizeof(SeqDesc)) || seqcnt.ensure((size_t)n_max * 8 + 64)) return make_err(LZ4F_ERROR_allocation_failed);

@@ -9,6 +9,7 @@
 #include "decode.cuh"
 #include "decode_2k.cuh"
 #include "decode_fused.cuh"
+#include "decode_linked.cuh"
 #include "encode.cuh"
 
 namespace lz4f {

@@ -483,3 +483,37 @@ def test_streaming_decompress_random_call_patterns(L, named_inputs):
             L.LZ4F_freeDecompressionContext(d)
             assert hint == 0, (si, trial)
             assert bytes(out) == want, (si, trial, len(out), len(want))
+
+
+# ------------------------------------------------------------------------------------------------
+# Linked frames go through the windowed kernel (decode_linked.cuh); frames it hands back (short blocks made by
+# autoFlush) go through the generic one.  Both must give liblz4's bytes; so must decoding a slab with history.
+def test_linked_frames_windowed_and_fallback(L, named_inputs):
+    st = datagen.structured(3 << 20, 3200)
+    s50 = named_inputs["synth50_8m"][:5 << 20]
+    cases = [
+        (oracle.conduit_compress(s50, oracle.mkprefs(bsid=4, indep=0)), s50),                                  # the reference's default framing
+        (oracle.conduit_compress(st, oracle.mkprefs(bsid=4, indep=0, bck=1, cck=1)), st),
+        (oracle.conduit_compress(st, oracle.mkprefs(bsid=6, indep=0)), st),
+        (oracle.conduit_compress(st, oracle.mkprefs(bsid=4, indep=0, autoflush=1), 50000), st),                # short blocks: fallback path
+        (oracle.conduit_compress(named_inputs["random10m"][:400000] + st[:300000], oracle.mkprefs(bsid=4, indep=0)), named_inputs["random10m"][:400000] + st[:300000]),  # stored blocks inside
+    ]
+    for i, (frame, want) in enumerate(cases):
+        out, used = gpu_decompress_frame(L, frame, len(want) + 8)
+        assert used == len(frame) and sha(out) == sha(want), i
+    # malformed linked frames: same verdicts as the oracle
+    base = cases[0][0]
+    for pos in (200, 5000, 70000, 140000, len(base) // 2):
+        bad = datagen.mutate(base, pos)
+        try:
+            want, _ = oracle.decompress_frame(bad, len(s50) + 8); verdict = "ok"
+        except oracle.OracleError as e:
+            want, verdict = None, str(e)
+        try:
+            got, _ = gpu_decompress_frame(L, bad, len(s50) + 8); gv = "ok"
+        except RuntimeError as e:
+            got, gv = None, str(e).split(" | ")[0]
+        if verdict == "ok":
+            assert gv == "ok" and got == want, (pos, gv)
+        else:
+            assert gv != "ok", (pos, verdict)
