@@ -233,7 +233,9 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
         const unsigned long long c0 = clock64();
         for (;;) {
             if (lds_peek(&sh.produced) > slot) break;
-            if (lds_peek(&sh.finished)) { if (lds_peek(&sh.produced) > slot) break; dump(); return; }
+            // the parser sets `finished` BEFORE it publishes a partial last slot: "finished and not yet produced" is not the
+            // end for that slot - total_slots (written before `finished`) says whether it is still to come
+            if (lds_peek(&sh.finished) && slot >= lds_peek(&sh.total_slots)) { dump(); return; }
             __builtin_amdgcn_s_sleep(4);
         }
         const unsigned long long c1 = clock64(); t_wait_p += c1 - c0; n_slots++;

@@ -3,7 +3,8 @@
 //
 // A linked frame is one chain: block k's matches reach into the last 64 KiB of blocks < k, so the blocks cannot go to
 // different workgroups.  decode_fused.cuh walks such a frame block by block with one parser wave, and every match copy
-// is a round trip to MALL/HBM (~3 us loaded, six in flight): ~1300 cycles per match, 0.8 GiB/s.  Here instead:
+// is a round trip to MALL/HBM (~3 us loaded, six in flight): ~1300 cycles per match, 0.8 GiB/s.  Here instead (3.5 GiB/s;
+// four parsers + three literal waves measured slower - the eight waves of the one CU share its scalar unit):
 //   * the last 128 KiB of output live in an LDS ring (`win`); a match copy is ds_read_b128 -> ds_write_b128 (+ the
 //     global store of the same registers), ~150 cycles, and LDS operations of a wave are performed in order, so
 //     dependent matches need no waiting at all;
@@ -11,10 +12,10 @@
 //     blocks at a time (each a scalar state machine like decode_fused's, descriptors with block-relative positions
 //     through its own LDS ring);
 //   * one CHAIN wave replays all matches in stream order out of the window;
-//   * four LITERAL waves copy the literal runs payload -> output and into the window, a ring slot each, up to 64 KiB
-//     ahead of the chain (a ring of 128 KiB: writing position x overwrites x - 128 KiB, which no match at or beyond
+//   * four LITERAL waves copy the literal runs payload -> output and into the window (run k of a slot -> wave k mod 4),
+//     up to 64 KiB ahead of the chain (a ring of 128 KiB: writing position x overwrites x - 128 KiB, which no match at or beyond
 //     `next_match_dst` can still want as long as x <= next_match_dst + 64 KiB).
-// Every wave walks every slot of every block in order (three counters), so block bases and the end of the frame need
+// Every wave walks every slot of every block in order, so block bases and the end of the frame need
 // no extra hand-off: the last sequence of a block is the one without a match.  Hand-offs are LDS words, no barriers.
 // Restriction: every block but the last must decode to exactly the block size (true for frames written without
 // LZ4F_flush / autoFlush); otherwise the kernel sets `*fallback` and leaves the frame to decode_fused.cuh.
@@ -230,14 +231,14 @@ __device__ __forceinline__ void lk_parser(LkShared& sh, LkRing& rg, uint32_t p, 
 
 // ---------------- what every consumer does: walk all slots of all blocks in order ----------------
 struct LkCursor {
-    uint32_t n0, n1, n2;             // next slot number per parser ring (scalars: a dynamically indexed array would live in scratch)
+    uint32_t n0, n1, n2, n3;         // next slot number per parser ring (scalars: a dynamically indexed array would live in scratch)
     uint32_t block;                  // current block
     uint64_t base;                   // absolute output position of its first byte
     uint32_t gslot;                  // slots seen so far (all rings)
-    __device__ __forceinline__ uint32_t next(uint32_t p) const { return p == 0 ? n0 : (p == 1 ? n1 : n2); }
-    __device__ __forceinline__ uint32_t bump(uint32_t p) { if (p == 0) return ++n0; if (p == 1) return ++n1; return ++n2; }
+    __device__ __forceinline__ uint32_t next(uint32_t p) const { return p == 0 ? n0 : (p == 1 ? n1 : (p == 2 ? n2 : n3)); }
+    __device__ __forceinline__ uint32_t bump(uint32_t p) { if (p == 0) return ++n0; if (p == 1) return ++n1; if (p == 2) return ++n2; return ++n3; }
 };
-static_assert(LK_PARSERS == 3, "LkCursor has three counters");
+static_assert(LK_PARSERS <= 4, "LkCursor has four counters");
 // waits for the next slot; false = stop (error elsewhere).  The slot stays valid until the caller bumps its `done` word.
 __device__ __forceinline__ bool lk_next_slot(LkShared& sh, LkCursor& c, uint32_t& p, uint32_t& idx, uint32_t& count)
 {
@@ -258,7 +259,7 @@ __device__ __forceinline__ void lk_literals(LkShared& sh, uint32_t me /* 0..LK_L
                                             uint8_t* out, uint32_t n, uint32_t block_size, uint64_t dst_cap)
 {
     const uint32_t lane = lane_id();
-    LkCursor c; c.n0 = c.n1 = c.n2 = 0; c.block = 0; c.base = 0; c.gslot = 0;
+    LkCursor c; c.n0 = c.n1 = c.n2 = c.n3 = 0; c.block = 0; c.base = 0; c.gslot = 0;
     while (c.block < n) {
         uint32_t p, idx, count;
         if (!lk_next_slot(sh, c, p, idx, count)) return;
@@ -376,7 +377,7 @@ __device__ __forceinline__ void lk_chain(LkShared& sh, uint8_t* out, BlockOut* _
                                          uint64_t hist0, uint32_t* __restrict__ fallback)
 {
     const uint32_t lane = lane_id();
-    LkCursor c; c.n0 = c.n1 = c.n2 = 0; c.block = 0; c.base = 0; c.gslot = 0;
+    LkCursor c; c.n0 = c.n1 = c.n2 = c.n3 = 0; c.block = 0; c.base = 0; c.gslot = 0;
     uint8_t* win = sh.win;
     while (c.block < n) {
         uint32_t p, idx, count;
@@ -399,21 +400,14 @@ __device__ __forceinline__ void lk_chain(LkShared& sh, uint8_t* out, BlockOut* _
             if (lane == 0) { sh.bad_block = c.block; sh.why = 8; sh.status = (bad_reach & first) ? -1 : -2; }
             return;
         }
-        // literal progress of the four literal waves, re-read from LDS only when the cached value does not cover run k
-        uint32_t prog[LK_LITS];
-#pragma unroll
-        for (int w = 0; w < LK_LITS; w++) prog[w] = 0;
-        auto lit_ready = [&](uint32_t k) -> bool {                            // waits; false = stop
+        // wait for literal run k (wave k % LK_LITS must have finished k / LK_LITS + 1 of its runs); false = stop
+        auto lit_ready = [&](uint32_t k) -> bool {
             const uint32_t w = k % LK_LITS, need = k / LK_LITS;
-            uint32_t have = w == 0 ? prog[0] : (w == 1 ? prog[1] : (w == 2 ? prog[2] : prog[3]));
-            for (uint32_t spin = 0; have <= need; spin++) {
-                have = lds_peek(&rg.lit_prog[idx][w]);
-                if (have > need) break;
+            for (uint32_t spin = 0; lds_peek(&rg.lit_prog[idx][w]) <= need; spin++) {
                 if ((int32_t)lds_peek((const uint32_t*)&sh.status) < 0) return false;
                 if (spin > LK_SPIN_MAX) { sh.bad_block = c.block; sh.why = 10; sh.status = -1; return false; }
                 __builtin_amdgcn_s_sleep(1);
             }
-            if (w == 0) prog[0] = have; else if (w == 1) prog[1] = have; else if (w == 2) prog[2] = have; else prog[3] = have;
             return true;
         };
         // one match, any shape: copy [dm - o, dm - o + m) -> [dm, dm + m) inside the window and to the output.  LDS operations
@@ -456,46 +450,54 @@ __device__ __forceinline__ void lk_chain(LkShared& sh, uint8_t* out, BlockOut* _
                 done += nn;
             }
         };
-        // Usual shape (16..1024 bytes, no self-overlap, no ring seam): up to four matches per LDS round trip - their reads are
-        // issued together when no source reaches the first one's destination - then written in order.
+        // Per lane, once per slot: is my match of the usual shape (16..1024 bytes, no self-overlap, not across the ring seam),
+        // and does its source end at or below the destination of the match three places earlier (then it can share an LDS
+        // round trip with up to three predecessors, whatever the grouping).
+        const uint32_t vsi = lk_widx(vdm - voff), vdi = lk_widx(vdm);
+        const bool usual = has && vml >= 16 && vml <= 1024 && voff >= vml && vsi + vml <= LK_WIN && vdi + vml <= LK_WIN;
+        const uint32_t dm3 = __shfl_up(vdm, 3);
+        const uint64_t usual_m = __ballot(usual);
+        const uint64_t join_m = __ballot(usual && lane >= 3 && vdm - voff + vml <= dm3) & usual_m;
+        // If the whole slot lies within 64 KiB of output, its literal runs can all be in the window before its first match:
+        // one wait per slot instead of one per match.
+        const uint32_t first_dst = (uint32_t)c.base + __builtin_amdgcn_readlane(vdst, 0);
+        const uint32_t last_end = (uint32_t)c.base + __builtin_amdgcn_readlane(vdst, count - 1) + __builtin_amdgcn_readlane(vlen, count - 1);
+        const bool whole = last_end - first_dst <= 65536;
+        if (whole) {
+            lds_poke(&sh.next_match_dst, first_dst);
+            for (uint32_t j = 0; j < LK_LITS && j < count; j++) if (!lit_ready(count - 1 - j)) return;     // the last run of each literal wave
+        }
         uint32_t k = 0;
         while (k < count) {
             const uint32_t m0 = __builtin_amdgcn_readlane(vml, k);
             if (m0 == 0) { k++; continue; }
-            const uint32_t dm0 = __builtin_amdgcn_readlane(vdm, k), o0 = __builtin_amdgcn_readlane(voff, k);
+            const uint32_t dm0 = __builtin_amdgcn_readlane(vdm, k);
             lds_poke(&sh.next_match_dst, dm0);
-            if (!lit_ready(k)) return;
-            auto simple = [&](uint32_t dm, uint32_t o, uint32_t m) -> bool {
-                return m >= 16 && m <= 1024 && o >= m && lk_widx(dm - o) + m <= LK_WIN && lk_widx(dm) + m <= LK_WIN;
-            };
-            if (!simple(dm0, o0, m0)) { copy_any(dm0, o0, m0); k++; continue; }
-            // gather up to three more
-            uint32_t dmv[4], ov[4], mv[4]; uint32_t nb = 1;
-            dmv[0] = dm0; ov[0] = o0; mv[0] = m0;
+            if (!whole && !lit_ready(k)) return;
+            if (!((usual_m >> k) & 1)) { copy_any(dm0, __builtin_amdgcn_readlane(voff, k), m0); k++; continue; }
+            // matches k .. k+nb-1 share one LDS round trip: the following ones must be `usual`, joinable, and - when literals
+            // are waited for one by one - their runs must have landed
+            uint32_t nb = 1;
+            {
+                const uint64_t run = ~((usual_m & join_m) >> (k + 1));        // first zero bit after k ends the group
+                const uint32_t can = run ? (uint32_t)__builtin_ctzll(run) : 63u;
+                nb += can < 3 ? can : 3;
+                if (k + nb > count) nb = count - k;
+                if (!whole) nb = 1;
+            }
+            uint32_t ra[4], pc[4], dmv[4];
 #pragma unroll
-            for (int j = 1; j < 4; j++) { dmv[j] = 0; ov[j] = 0; mv[j] = 0; }
-#pragma unroll
-            for (int j = 1; j < 4; j++) {
-                const uint32_t kk = k + j;
-                if (nb == (uint32_t)j && kk < count) {
-                    const uint32_t m = __builtin_amdgcn_readlane(vml, kk), dm = __builtin_amdgcn_readlane(vdm, kk), o = __builtin_amdgcn_readlane(voff, kk);
-                    // (the run in front of it must be in the window already: peek without waiting)
-                    const uint32_t w = kk % LK_LITS, need = kk / LK_LITS;
-                    uint32_t have = w == 0 ? prog[0] : (w == 1 ? prog[1] : (w == 2 ? prog[2] : prog[3]));
-                    if (have <= need) { have = lds_peek(&rg.lit_prog[idx][w]); if (w == 0) prog[0] = have; else if (w == 1) prog[1] = have; else if (w == 2) prog[2] = have; else prog[3] = have; }
-                    if (m != 0 && have > need && simple(dm, o, m) && dm - o + m <= dm0) { dmv[j] = dm; ov[j] = o; mv[j] = m; nb = j + 1; }
-                }
+            for (int j = 0; j < 4; j++) {
+                const uint32_t kk = (uint32_t)j < nb ? k + j : k;
+                const uint32_t m = __builtin_amdgcn_readlane(vml, kk);
+                const uint32_t nfull = m >> 4, tail = m & 15;
+                const bool act = (uint32_t)j < nb && (lane < nfull || (lane == nfull && tail));
+                pc[j] = act ? (lane < nfull ? lane * 16 : m - 16) : 0xFFFFFFFFu;            // my piece of match j, or none
+                ra[j] = act ? __builtin_amdgcn_readlane(vsi, kk) + pc[j] : 0u;
+                dmv[j] = __builtin_amdgcn_readlane(vdm, kk);
             }
             // (all four reads are issued by every lane, idle ones at window index 0: a read behind a branch would let the
             // compiler merge its result with another value BEFORE the wait below - it does not know the read is asynchronous)
-            uint32_t ra[4], pc[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t nfull = mv[j] >> 4, tail = mv[j] & 15;
-                const bool act = (uint32_t)j < nb && (lane < nfull || (lane == nfull && tail));
-                pc[j] = act ? (lane < nfull ? lane * 16 : mv[j] - 16) : 0xFFFFFFFFu;       // my piece of match j, or none
-                ra[j] = act ? lk_widx(dmv[j] - ov[j]) + pc[j] : 0u;
-            }
             const lk_v4 v0 = lk_win_read16_nowait(win, ra[0]), v1 = lk_win_read16_nowait(win, ra[1]);
             const lk_v4 v2 = lk_win_read16_nowait(win, ra[2]), v3 = lk_win_read16_nowait(win, ra[3]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -540,11 +542,11 @@ __global__ __launch_bounds__(64 * LK_WAVES) void k_decode_linked(const uint8_t* 
     __syncthreads();
     if (n == 0) return;
     if (wave < LK_PARSERS) {
-        __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(2);
         lk_parser(sh, sh.ring[wave], wave, frame, table, n, block_size, dst_cap);
         __builtin_amdgcn_s_setprio(0);
     } else if (wave == LK_PARSERS) {
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio(3);                                       // the chain wave is the critical path of a linked frame
         lk_chain(sh, dst, table, n, block_size, dst_cap, hist0, fallback);
         __builtin_amdgcn_s_setprio(0);
     } else {

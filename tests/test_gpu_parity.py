@@ -280,10 +280,11 @@ def test_full_size_properties_1gib(L):
     r = eng.result()
     ratio = n / r.size
     assert 1.7 < ratio < 2.2, ratio                      # liblz4: 1.944 on this recipe
-    back = torch.empty_like(src)
-    eng.decompress_blocks_async(frame, r.size, back, table, nb, p.frameInfo)
-    r2 = eng.result()
-    assert r2.size == n and torch.equal(back, src)
+    for rep in range(4):                                  # (repeated, into uninitialised memory: the hand-offs inside the decoder are timing-sensitive)
+        back = torch.empty_like(src)
+        eng.decompress_blocks_async(frame, r.size, back, table, nb, p.frameInfo)
+        r2 = eng.result()
+        assert r2.size == n and torch.equal(back, src), rep
     offs = np.arange(nb, dtype=np.uint64) << 22
     lens = np.full(nb, 1 << 22, dtype=np.uint32)
     a, b = eng.xxh32(src, offs, lens), eng.xxh32(back, offs, lens)
