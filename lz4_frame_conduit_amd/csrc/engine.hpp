@@ -83,7 +83,7 @@ struct lz4f_mi355x_engine {
     // Encode `n` bytes at src (host) as frame blocks of block_size (last may be short); `hist` bytes of
     // history (host) precede them when linked.  Appends [size word][payload][checksum] per block to out.
     size_t compress_blocks_host(const uint8_t* src, size_t n, const uint8_t* hist, size_t hist_len,
-                                uint32_t block_size, bool linked, bool block_checksum, std::vector<uint8_t>& out);
+                                uint32_t block_size, bool linked, bool block_checksum, uint8_t* dst, size_t dst_cap, size_t* written);
     // Decode one compressed block payload (host; followed by its 4-byte checksum when bck) with `hist_len`
     // bytes of history (host, linked frames).  The checksum is verified and the block decoded on the GPU;
     // the decoded bytes land in dst (host).

@@ -159,7 +159,7 @@ struct LZ4F_cctx_s {
     size_t block_size;
     std::vector<uint8_t> tmp;        // staged input, always < block_size between calls
     std::vector<uint8_t> hist;       // last <= 64 KiB of input already encoded (linked mode)
-    std::vector<uint8_t> work, out;
+    std::vector<uint8_t> work;
     uint64_t total_in;
     Xxh32State xxh;
 };
@@ -178,14 +178,12 @@ static size_t encode_blocks(LZ4F_cctx_s* c, uint8_t* dst, size_t cap, const uint
     lz4f_mi355x_engine* eng;
     size_t r = thread_engine(&eng);
     if (is_err(r)) return r;
-    c->out.clear();
+    size_t written = 0;
     r = eng->compress_blocks_host(src, n, c->hist.data(), c->hist.size(), (uint32_t)c->block_size,
-                                  c->prefs.frameInfo.blockMode == LZ4F_blockLinked, c->prefs.frameInfo.blockChecksumFlag != 0, c->out);
+                                  c->prefs.frameInfo.blockMode == LZ4F_blockLinked, c->prefs.frameInfo.blockChecksumFlag != 0, dst, cap, &written);
     if (is_err(r)) return r;
-    if (c->out.size() > cap) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
-    memcpy(dst, c->out.data(), c->out.size());
     push_history(c, src, n);
-    return c->out.size();
+    return written;
 }
 
 extern "C" {
