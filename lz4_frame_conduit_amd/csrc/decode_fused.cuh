@@ -30,6 +30,9 @@ template <int W> struct FzCfg;
 template <> struct FzCfg<8> { static constexpr int WAVES = 8; static constexpr uint32_t STAGE = 8192, RING = 8, LDS_BUDGET = 40960; };
 template <> struct FzCfg<4> { static constexpr int WAVES = 4; static constexpr uint32_t STAGE = 2048, RING = 4, LDS_BUDGET = 20480; };
 constexpr uint32_t FZ_OVER = 576;                // >= the parser's 520-byte register window + 8
+#ifndef FZ_FED_DEPTH
+#define FZ_FED_DEPTH 4
+#endif
 constexpr int      FZ_MATCH_SET = 3;            // match copies per register set (two sets in flight)
 
 template <class C>
@@ -220,14 +223,69 @@ __device__ __forceinline__ void fz_parser(FzShared<C>& sh, const uint8_t* __rest
     if (prof && blockIdx.x == 0 && lane == 0) { prof[0] = clock64() - t_begin; prof[1] = t_ring; prof[2] = nseq; }
 }
 
-// ---------------- copier waves ----------------
+// ---------------- feeder wave (indexed decode, decode_indexed.cuh) ----------------
+// The block's descriptors already exist in HBM (k_parse_indexed wrote them, one lane per index entry): wave 0 only moves
+// them into the ring, 64 at a time, and checks what needs output positions -- they must tile [0, size) without gaps,
+// stay inside the block's capacity, and every match must start at or behind the first byte of the block.
+// Descriptor word 3 carries, besides the match length, the DIRECT flag (bit 31): the match's bytes are known to sit in
+// the payload at the 23-bit position that then replaces the offset, so the copiers treat it like a literal run.
 template <class C>
+__device__ __forceinline__ void fz_feeder(FzShared<C>& sh, const SeqDesc* __restrict__ desc, const uint32_t* __restrict__ dsrc, uint32_t nseq,
+                                          uint32_t csize, uint32_t cap)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t nslots = (nseq + 63) >> 6;
+    uint32_t expect = 0, status = nseq ? 0u : 1u, published = 0;
+    uint4 nxt = {0u, 0u, 0u, 0u};
+    uint32_t nxt_src = 0xFFFFFFFFu;
+    if (lane < nseq) { nxt = ((const uint4*)desc)[lane]; if (dsrc) nxt_src = dsrc[lane]; }
+    for (uint32_t slot = 0; slot < nslots && !status; slot++) {
+        const uint32_t count = (nseq - slot * 64 < 64) ? nseq - slot * 64 : 64;
+        uint4 d = nxt;
+        if (nxt_src < (1u << 23) && !(d.w >> 31) && (d.w & 0xFFFFFFu))      // k_resolve_direct found the match's bytes in the payload
+            d = uint4{(d.x & 0xFFFFFFu) | ((nxt_src & 0xFFu) << 24), (d.y & 0xFFFFFFu) | (((nxt_src >> 8) & 0xFFu) << 24), d.z,
+                      (d.w & 0xFFFFFFu) | 0x80000000u | ((nxt_src >> 16) << 24)};
+        const uint32_t nx = (slot + 1) * 64 + lane;
+        nxt = uint4{0u, 0u, 0u, 0u}; nxt_src = 0xFFFFFFFFu;
+        if (nx < nseq) { nxt = ((const uint4*)desc)[nx]; if (dsrc) nxt_src = dsrc[nx]; }    // next slot's descriptors travel while this one is checked and published
+        const uint32_t p = d.x & 0xFFFFFFu, lit = d.y & 0xFFFFFFu, op = d.z, ml = d.w & 0xFFFFFFu;
+        const bool direct = (d.w >> 31) != 0;
+        const uint32_t f24 = (d.x >> 24) | ((d.y >> 24) << 8) | (((d.w >> 24) & 0x7Fu) << 16);
+        const uint64_t dm = (uint64_t)op + lit, end = dm + ml;
+        const uint32_t prev_end = __shfl_up((uint32_t)end, 1);
+        const bool last = slot * 64 + lane + 1 == nseq;
+        bool bad = op != (lane == 0 ? expect : prev_end) || (uint64_t)p + lit > csize || end > cap;
+        if (last) bad |= ml != 0 || direct;
+        else {
+            bad |= ml < 4 || end + 5 > cap;
+            bad |= direct ? ((uint64_t)f24 + ml > csize) : (f24 == 0 || f24 > 65535u || f24 > dm);
+        }
+        if (__ballot(lane < count && bad)) { status = 1; break; }
+        expect = __shfl((uint32_t)end, (int)count - 1);
+        while (slot >= lds_peek(&sh.match_done) + C::RING) __builtin_amdgcn_s_sleep(8);          // ring full: wait for the oldest slot
+        sh.ring[slot % C::RING][lane] = d;
+        if (slot + 1 == nslots) break;                                       // the last slot is published after the totals (see fz_parser)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_poke(&sh.produced, slot + 1);
+        published = slot + 1;
+    }
+    sh.total_slots = status ? published : nslots;
+    sh.last_count = status ? 64u : nseq - (nslots - 1) * 64;
+    sh.out_size = expect;
+    sh.status = status ? -1 : 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds_poke(&sh.finished, 1u);
+    if (!status) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lds_poke(&sh.produced, nslots); }
+}
+
+// ---------------- copier waves ----------------
+template <class C, bool FED = false>
 __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __restrict__ in, uint8_t* out, uint32_t cw /* 0..6 */,
                                           const uint8_t* safe /* 16 readable bytes */, unsigned long long* prof)
 {
     const uint32_t lane = lane_id();
-    unsigned long long t_wait_p = 0, t_lit = 0, t_wait_m = 0, t_match = 0, n_slots = 0;
-    auto dump = [&]() { if (prof && blockIdx.x == 0 && lane == 0) { unsigned long long* o = prof + 8 * (cw + 1); o[0] = t_wait_p; o[1] = t_lit; o[2] = t_wait_m; o[3] = t_match; o[4] = n_slots; } };
+    unsigned long long t_wait_p = 0, t_lit = 0, t_wait_m = 0, t_match = 0, n_slots = 0, t_dep = 0, t_drain = 0;
+    auto dump = [&]() { if (prof && blockIdx.x == 0 && lane == 0) { unsigned long long* o = prof + 8 * (cw + 1); o[0] = t_wait_p; o[1] = t_lit; o[2] = t_wait_m; o[3] = t_match; o[4] = n_slots; o[5] = t_dep; o[6] = t_drain; } };
     for (uint32_t slot = cw;; slot += C::WAVES - 1) {
         // wait for the slot (or for the end of the block)
         const unsigned long long c0 = clock64();
@@ -245,42 +303,59 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
         uint32_t count = 64;
         if (lds_peek(&sh.finished) && slot + 1 == lds_peek(&sh.total_slots)) count = lds_peek(&sh.last_count);
         count = uni(count);
-        const uint32_t vsrc = d.x & 0xFFFFFFu, vlen = d.y & 0xFFFFFFu, vdst = d.z, vml = d.w, voff = (d.x >> 24) | ((d.y >> 24) << 8);
+        const uint32_t vsrc = d.x & 0xFFFFFFu, vlen = d.y & 0xFFFFFFu, vdst = d.z, vml = FED ? (d.w & 0xFFFFFFu) : d.w, voff = (d.x >> 24) | ((d.y >> 24) << 8);
+        // fed descriptors: a DIRECT match is one more copy out of the payload (position in the bits of the offset + 7 more)
+        const bool vdirect = FED && lane < count && (d.w >> 31) != 0;
+        const uint32_t vmsrc = voff | (((d.w >> 24) & 0x7Fu) << 16);
+        const uint64_t direct_m = FED ? __ballot(vdirect) : 0ull;
 
         // ---- (1) literals: no dependencies.  Software pipeline, two jobs per stage, two stages: the loads of the next two
         // pieces are issued before the stores of the current two, with hand-counted waits (see common.cuh).
         {
-            uint32_t k = 0, off = 0;                                     // scalar iterator over (descriptor, 1 KiB round)
+            uint32_t k = 0, off = 0, part = 0;                           // scalar iterator over (descriptor, literal run / direct match, 1 KiB round)
             auto next_job = [&]() -> CopyJob {
                 for (;;) {
                     if (k >= count) return CopyJob{safe, out, 0};
-                    const uint32_t len = __builtin_amdgcn_readlane(vlen, k);
+                    uint32_t len = __builtin_amdgcn_readlane(vlen, k);
                     const uint8_t* sp = in + __builtin_amdgcn_readlane(vsrc, k);
                     uint8_t* dp = out + __builtin_amdgcn_readlane(vdst, k);
+                    if (FED && part) { dp += len; len = __builtin_amdgcn_readlane(vml, k); sp = in + __builtin_amdgcn_readlane(vmsrc, k); }
+                    auto advance = [&]() { off = 0; if (FED && part == 0 && ((direct_m >> k) & 1)) part = 1; else { part = 0; k++; } };
                     if (len < 16) {                                      // tiny run: bytewise, right now
                         if (lane < len) dp[lane] = sp[lane];
-                        k++; off = 0; continue;
+                        advance(); continue;
                     }
                     uint32_t o = off, n = len - off;
                     if (n > 1024) n = 1024;
                     if (n < 16) { o = len - 16; n = 16; }                // ragged end of a long run: overlap backwards
                     off += 1024;
-                    if (off >= len) { k++; off = 0; }
+                    if (off >= len) advance();
                     return CopyJob{sp + o, dp + o, n};
                 }
             };
-            // ping-pong: set A = (a0,a1 / pa0,pa1), set B = (b0,b1 / pb0,pb1); no register moves between stages
-            CopyJob a0 = next_job(), a1 = next_job(), b0, b1;
-            Piece pa0, pa1, pb0, pb1;
-            job_load(pa0, a0, safe); job_load(pa1, a1, safe);
-            while (a0.n) {
-                b0 = next_job(); b1 = next_job();
-                job_load(pb0, b0, safe); job_load(pb1, b1, safe);
-                job_store(a0, pa0); job_store(a1, pa1);
-                if (b0.n == 0) break;
-                a0 = next_job(); a1 = next_job();
-                job_load(pa0, a0, safe); job_load(pa1, a1, safe);
-                job_store(b0, pb0); job_store(b1, pb1);
+            // ping-pong: two register sets of NL jobs; no register moves between stages.  Fed descriptors leave the copiers as
+            // the only limit of a block, and then the bytes in flight per wave are what counts: twice the depth
+            constexpr int NL = FED ? FZ_FED_DEPTH : 2;
+            CopyJob A[NL], B[NL];
+            Piece PA[NL], PB[NL];
+#pragma unroll
+            for (int i = 0; i < NL; i++) A[i] = next_job();
+#pragma unroll
+            for (int i = 0; i < NL; i++) job_load(PA[i], A[i], safe);
+            while (A[0].n) {
+#pragma unroll
+                for (int i = 0; i < NL; i++) B[i] = next_job();
+#pragma unroll
+                for (int i = 0; i < NL; i++) job_load(PB[i], B[i], safe);
+#pragma unroll
+                for (int i = 0; i < NL; i++) job_store(A[i], PA[i]);
+                if (B[0].n == 0) break;
+#pragma unroll
+                for (int i = 0; i < NL; i++) A[i] = next_job();
+#pragma unroll
+                for (int i = 0; i < NL; i++) job_load(PA[i], A[i], safe);
+#pragma unroll
+                for (int i = 0; i < NL; i++) job_store(B[i], PB[i]);
             }
         }
         // ---- (2) matches, in stream order, after every earlier slot's matches ----
@@ -290,7 +365,7 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
             if ((int32_t)lds_peek((const uint32_t*)&sh.status) < 0) { dump(); return; }
             __builtin_amdgcn_s_sleep(2);
         }
-        const unsigned long long c3 = clock64(); t_wait_m += c3 - c2;
+        __builtin_amdgcn_sched_barrier(0); const unsigned long long c3 = clock64(); t_wait_m += c3 - c2; __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(2);                                       // the match phases form the second serial chain of a block
         {
             // Out-of-order replay.  A match may be copied as soon as every EARLIER match of this slot whose destination
@@ -304,7 +379,7 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
             const uint32_t mdm = vdst + vlen;                                   // my match's destination, source = mdm - voff
             // signed: a source may start in the history in front of a linked block (negative) and end inside the block
             const int32_t ms0 = (int32_t)mdm - (int32_t)voff, ms1 = ms0 + (int32_t)vml;
-            const bool has = lane < count && vml != 0;
+            const bool has = lane < count && vml != 0 && !vdirect;             // direct matches went out with the literals
             const uint64_t fastmask = __ballot(has && vml >= 16 && vml <= 1024 && voff >= vml);   // one non-overlapping round
             uint32_t dep_lo = 0, dep_hi = 0;
             for (uint32_t k = 0; k < count && k < 32; k++) {
@@ -316,6 +391,7 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
                 dep_hi |= (k < lane && mk != 0 && ms0 < (int32_t)(dk + mk) && ms1 > (int32_t)dk) ? (1u << (k - 32)) : 0u;
             }
             uint64_t todo = __ballot(has), unstored = todo;
+            __builtin_amdgcn_sched_barrier(0); t_dep += clock64() - c3; __builtin_amdgcn_sched_barrier(0);
             auto ready = [&]() -> uint64_t {
                 return __ballot(has && ((dep_lo & (uint32_t)unstored) | (dep_hi & (uint32_t)(unstored >> 32))) == 0) & todo;
             };
@@ -369,7 +445,13 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
             }
         }
         // ---- (3) everything this slot wrote is in memory: let the next slot's matches go ----
+        __builtin_amdgcn_sched_barrier(0);
+        const unsigned long long c5 = clock64();
+        __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        t_drain += clock64() - c5;
+        __builtin_amdgcn_sched_barrier(0);
         lds_poke(&sh.match_done, slot + 1);
         __builtin_amdgcn_s_setprio(0);
         t_match += clock64() - c3;
@@ -377,9 +459,10 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
 }
 
 // Decode one compressed block with the whole workgroup; returns decoded size or -1 (same value in all threads).
-template <class C>
+template <class C, bool FED = false>
 __device__ __forceinline__ int32_t fz_decode_block(FzShared<C>& sh, const uint8_t* __restrict__ in, uint32_t csize, uint8_t* out, uint32_t cap, uint64_t hist,
-                                                   const uint8_t* safe, unsigned long long* prof)
+                                                   const uint8_t* safe, unsigned long long* prof, const SeqDesc* __restrict__ fed = nullptr, uint32_t nfed = 0,
+                                                   const uint32_t* __restrict__ fed_src = nullptr)
 {
     const uint32_t wave = uni(threadIdx.x >> 6);
     __syncthreads();                                                     // previous block's LDS state is dead
@@ -387,10 +470,11 @@ __device__ __forceinline__ int32_t fz_decode_block(FzShared<C>& sh, const uint8_
     __syncthreads();
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);                                   // the serial chain: win issue arbitration against the 7 copier waves of this SIMD
-        fz_parser<C>(sh, in, csize, cap, hist, prof);
+        if (FED) fz_feeder<C>(sh, fed, fed_src, nfed, csize, cap);
+        else fz_parser<C>(sh, in, csize, cap, hist, prof);
         __builtin_amdgcn_s_setprio(0);
     }
-    else fz_copier<C>(sh, in, out, wave - 1, safe, prof);
+    else fz_copier<C, FED>(sh, in, out, wave - 1, safe, prof);
     __syncthreads();                                                     // all copies of this block are issued and complete
     const int32_t st = (int32_t)uni((uint32_t)sh.status);
     const uint32_t osz = uni(sh.out_size);

@@ -1,0 +1,278 @@
+// decode_indexed.cuh -- decode of big independent blocks with a SEQUENCE INDEX from the compressor
+// (DESIGN.md section 8 item 1).
+//
+// The scalar parser of decode_fused.cuh costs ~200 scalar instructions per sequence and a CU has one scalar unit:
+// however the waves are arranged, the GPU parses the headline workload in >= 2 ms.  A lane-per-entry walk of the same
+// chains needs entry points.  The compressor has them for free: pass E1 works on 128 KiB chunks, so for every chunk
+// that found matches pass S knows where its first token sits in the block's payload, which output position that
+// sequence starts at, and how many sequences follow until the next such chunk.  That table (16 bytes per chunk) is the
+// index; frames stay plain LZ4 frames, and a frame without an index (or with one that does not fit) is decoded by the
+// generic kernels.
+//   k_build_index     (compress side, after k_layout) entries per chunk, descriptor base per block, total count
+//   k_parse_indexed   one LANE per entry: walks its sequences in the payload and writes 16-byte descriptors
+//                     {literal source, literal length, output position, match length, offset} to HBM; checks that
+//                     it ends exactly where the next entry starts (else the index is declared unusable)
+//                     A match whose source lies inside a recent literal run (or inside such a match) is marked
+//                     DIRECT: its bytes are in the payload, so it is copied like a literal run, in any order.
+//   k_resolve_direct  one lane per sequence: matches whose source lies in a literal run further back (binary search over
+//                     the block's descriptors, following plain matches a few hops) become direct as well
+//   k_copy_indexed    one workgroup per block: the copier waves of decode_fused.cuh, fed with those descriptors by
+//                     wave 0 instead of by a parser wave; only the matches that are not direct form a chain.
+#pragma once
+#include "common.cuh"
+#include "decode.cuh"
+#include "decode_2k.cuh"
+#include "decode_fused.cuh"
+#include "decode_linked.cuh"
+#include "encode.cuh"
+
+namespace lz4f {
+
+// 8 payload bytes at `pos`, never touching memory at or beyond in + readable
+__device__ __forceinline__ uint64_t pt_load8(const uint8_t* __restrict__ in, uint32_t pos, uint64_t readable)
+{
+    if ((uint64_t)pos + 8 <= readable) { typedef uint64_t u64u __attribute__((aligned(1))); return *(const u64u*)(in + pos); }
+    uint64_t v = 0;
+    for (uint32_t i = 0; i < 8; i++) if ((uint64_t)pos + i < readable) v |= (uint64_t)in[pos + i] << (8 * i);
+    return v;
+}
+
+constexpr uint32_t IX_MAGIC = 0x3158494Cu;                     // "LIX1"
+struct IxHeader { uint32_t magic, n_blocks, chunks_per_block, total_seqs; };
+struct IxBlock  { uint32_t seq_base, nseq; };                  // first descriptor of the block; 0 sequences: stored block / not indexed
+struct IxEntry  { uint32_t in_off, out_pos, seq_off, nseq; };  // per chunk; nseq == 0: no entry
+__host__ __device__ inline size_t ix_bytes(uint32_t n_blocks, uint32_t chunks_per_block)
+{
+    return sizeof(IxHeader) + (size_t)n_blocks * sizeof(IxBlock) + (size_t)n_blocks * chunks_per_block * sizeof(IxEntry);
+}
+__device__ __forceinline__ IxBlock* ix_blocks(void* ix) { return (IxBlock*)((uint8_t*)ix + sizeof(IxHeader)); }
+__device__ __forceinline__ IxEntry* ix_entries(void* ix, uint32_t n_blocks) { return (IxEntry*)((uint8_t*)ix + sizeof(IxHeader) + (size_t)n_blocks * sizeof(IxBlock)); }
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_build_index(EncGeom g, const ChunkInfo* __restrict__ info, const BlockOut* __restrict__ table,
+                                                      const ResultRec* __restrict__ res, void* __restrict__ ix)
+{
+    __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_carry;
+    const uint32_t t = threadIdx.x;
+    IxHeader* hd = (IxHeader*)ix;
+    IxBlock* blocks = ix_blocks(ix);
+    IxEntry* entries = ix_entries(ix, g.n_blocks);
+    const bool usable = res->status == ST_OK && !g.linked;
+    // 1) per block: entries of its chunks, sequence count
+    for (uint32_t b = t; b < g.n_blocks; b += 1024) {
+        const BlockOut e = table[b];
+        const ChunkInfo* ci = info + (uint64_t)b * g.chunks_per_block;
+        IxEntry* en = entries + (uint64_t)b * g.chunks_per_block;
+        const uint32_t blen = e.dst_size;
+        const uint32_t nch = (blen + g.chunk_size - 1) / g.chunk_size;
+        uint32_t nseq = 0, last = 0xFFFFFFFFu;
+        for (uint32_t c = 0; c < g.chunks_per_block; c++) {
+            IxEntry x{0, 0, 0, 0};
+            if (usable && !(e.word >> 31) && c < nch && ci[c].nrec) {
+                x.in_off = (uint32_t)(ci[c].out_off - e.src_off);          // the chunk's first token (pass E2 starts writing there)
+                x.out_pos = c * g.chunk_size - ci[c].carry_in;             // its literal run starts with the literals carried in
+                x.seq_off = nseq; x.nseq = ci[c].nrec;
+                nseq += ci[c].nrec; last = c;
+            }
+            en[c] = x;
+        }
+        if (last != 0xFFFFFFFFu) { en[last].nseq += 1; nseq += 1; }        // the block's final literal-only sequence
+        blocks[b].nseq = nseq;
+    }
+    __syncthreads();
+    // 2) exclusive scan of the per-block counts in tiles of 1024
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < g.n_blocks; base += 1024) {
+        const uint32_t b = base + t;
+        const uint32_t v = (b < g.n_blocks) ? blocks[b].nseq : 0;
+        s_part[t] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            const uint32_t add = (t >= off) ? s_part[t - off] : 0;
+            __syncthreads();
+            s_part[t] += add;
+            __syncthreads();
+        }
+        if (b < g.n_blocks) blocks[b].seq_base = s_carry + s_part[t] - v;
+        __syncthreads();
+        if (t == 1023) s_carry += s_part[1023];
+        __syncthreads();
+    }
+    if (t == 0) { hd->magic = usable ? IX_MAGIC : 0u; hd->n_blocks = g.n_blocks; hd->chunks_per_block = g.chunks_per_block; hd->total_seqs = s_carry; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One lane per index entry.  Input-side rules only (the copy kernel checks the ones that need output positions).
+// `flags[0]` is set when anything disagrees with the index: the caller then falls back to the generic decoder.
+__global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
+                                                       void* __restrict__ ix, uint32_t n_blocks, uint32_t chunks_per_block,
+                                                       SeqDesc* __restrict__ desc, uint64_t desc_cap, uint32_t* __restrict__ flags)
+{
+    const uint64_t cidx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (cidx >= (uint64_t)n_blocks * chunks_per_block) return;
+    const uint32_t b = (uint32_t)(cidx / chunks_per_block), c = (uint32_t)(cidx % chunks_per_block);
+    const IxEntry* en = ix_entries(ix, n_blocks) + (uint64_t)b * chunks_per_block;
+    const IxEntry me = en[c];
+    if (me.nseq == 0) return;
+    const IxBlock blk = ix_blocks(ix)[b];
+    const BlockOut e = table[b];
+    const uint32_t csize = e.word & 0x7FFFFFFFu;
+    bool bad = (e.word >> 31) != 0 || e.src_off + csize > frame_cap || me.in_off >= csize || (uint64_t)blk.seq_base + me.seq_off + me.nseq > desc_cap;
+    // where the next entry of this block starts (or the payload ends)
+    uint32_t stop = csize; bool is_tail = true, is_head = true;
+    for (uint32_t k = c + 1; k < chunks_per_block; k++) if (en[k].nseq) { stop = en[k].in_off; is_tail = false; break; }
+    for (uint32_t k = 0; k < c; k++) if (en[k].nseq) { is_head = false; break; }
+    if (is_head && (me.in_off != 0 || me.out_pos != 0 || me.seq_off != 0)) bad = true;      // the entries must cover the payload from its first byte
+    if (bad) { atomicOr(flags, 1u); return; }
+    const uint8_t* in = frame + e.src_off;
+    const uint64_t readable = frame_cap - e.src_off;
+    SeqDesc* out = desc + blk.seq_base + me.seq_off;
+    uint32_t pos = me.in_off, op = me.out_pos;
+    // the last four output ranges whose bytes are known to sit in the payload (literal runs, and matches that copied from such a
+    // range): a match that lies inside one is DIRECT -- a plain copy out of the payload that needs no earlier output
+    uint32_t r0o = 0, r0n = 0, r0p = 0, r1o = 0, r1n = 0, r1p = 0, r2o = 0, r2n = 0, r2p = 0, r3o = 0, r3n = 0, r3p = 0;
+    auto remember = [&](uint32_t o, uint32_t n, uint32_t pp) { r3o = r2o; r3n = r2n; r3p = r2p; r2o = r1o; r2n = r1n; r2p = r1p; r1o = r0o; r1n = r0n; r1p = r0p; r0o = o; r0n = n; r0p = pp; };
+    for (uint32_t i = 0; i < me.nseq; i++) {
+        if (pos >= csize) { bad = true; break; }
+        const uint64_t w = pt_load8(in, pos, readable);
+        const uint32_t token = (uint32_t)w & 0xFF;
+        uint32_t lit = token >> 4, p = pos + 1;
+        if (lit == 15) {
+            const uint64_t x = w >> 8;
+            const uint32_t f = (uint32_t)__builtin_ctzll(~x), k = f >> 3;
+            if (k < 7) { lit += 255u * k + (uint32_t)((x >> (f & 56u)) & 0xFF); p += k + 1; }
+            else { for (;;) { if (p >= csize || lit > (1u << 24)) { bad = true; break; } const uint32_t v = in[p++]; lit += v; if (v != 255) break; } if (bad) break; }
+        }
+        if (p > csize || lit >= (1u << 24)) { bad = true; break; }
+        const uint32_t in_left = csize - p;
+        uint32_t mlen = 0, off = 0;
+        if (lit + 8 > in_left) {                                               // the block's last sequence
+            if (lit != in_left || !is_tail || i + 1 != me.nseq) { bad = true; break; }
+            pos = csize;
+        } else {
+            const uint32_t q = p + lit;
+            const uint64_t w2 = pt_load8(in, q, readable);
+            off = (uint32_t)w2 & 0xFFFF;
+            if (off == 0) { bad = true; break; }
+            mlen = token & 15; uint32_t pn = q + 2;
+            if (mlen == 15) {
+                const uint64_t x = w2 >> 16;
+                const uint32_t f = (uint32_t)__builtin_ctzll(~x), k = f >> 3;
+                if (k < 6) { mlen += 255u * k + (uint32_t)((x >> (f & 56u)) & 0xFF); pn += k + 1; }
+                else { for (;;) { if (pn >= csize || mlen > (1u << 24)) { bad = true; break; } const uint32_t v = in[pn++]; mlen += v; if (v != 255) break; } if (bad) break; }
+                if (pn + 4 >= csize) { bad = true; break; }
+            }
+            mlen += 4;
+            pos = pn;
+        }
+        uint32_t f24 = off, mw = mlen;
+        if (lit) remember(op, lit, p);
+        if (mlen) {
+            const uint32_t dm = op + lit;
+            if (off > dm) { bad = true; break; }
+            const uint32_t s0 = dm - off;
+            uint32_t msrc = 0xFFFFFFFFu;
+            if (mlen <= off) {
+                if (s0 >= r0o && s0 + mlen <= r0o + r0n) msrc = r0p + (s0 - r0o);
+                else if (s0 >= r1o && s0 + mlen <= r1o + r1n) msrc = r1p + (s0 - r1o);
+                else if (s0 >= r2o && s0 + mlen <= r2o + r2n) msrc = r2p + (s0 - r2o);
+                else if (s0 >= r3o && s0 + mlen <= r3o + r3n) msrc = r3p + (s0 - r3o);
+            }
+            if (msrc < (1u << 23)) { f24 = msrc; mw |= 0x80000000u; remember(dm, mlen, msrc); }
+        }
+        out[i] = SeqDesc{p | ((f24 & 0xFFu) << 24), lit | (((f24 >> 8) & 0xFFu) << 24), op, mw | (((f24 >> 16) & 0x7Fu) << 24)};
+        op += lit + mlen;
+    }
+    if (!bad && pos != stop) bad = true;                                       // must end exactly where the next entry starts
+    if (bad) atomicOr(flags, 1u);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// One lane per sequence: where in the PAYLOAD do the bytes of my match come from?  The lane looks up the sequence that
+// produced its first source byte (binary search over the block's descriptors, which are sorted by output position).  Inside
+// that sequence's literal run: found.  Inside its match (not overlapping itself): the same question one offset further back,
+// a few hops at most.  Anything else (a source that straddles two runs, run-length matches) stays a match for the chain.
+// The descriptors are only read here; the answer goes to dsrc[i] (IX_NOT_DIRECT = none) and the feeder wave merges it in.
+constexpr uint32_t IXR_WGS = 16;                                // workgroups per block (grid-stride over its sequences)
+constexpr uint32_t IXR_HOPS = 6;
+constexpr uint32_t IX_NOT_DIRECT = 0xFFFFFFFFu;
+__global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, const ResultRec* __restrict__ res, uint32_t n_max,
+                                                        const SeqDesc* __restrict__ desc, uint32_t* __restrict__ dsrc, uint64_t desc_cap,
+                                                        uint32_t* __restrict__ flags, uint32_t count_it)
+{
+    if (res->status != ST_OK || *flags) return;
+    const uint32_t b = blockIdx.y;
+    const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    if (b >= n) return;
+    const IxBlock blk = ix_blocks(ix)[b];
+    if ((uint64_t)blk.seq_base + blk.nseq > desc_cap) return;
+    const SeqDesc* bd = desc + blk.seq_base;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < blk.nseq; i += IXR_WGS * 256) {
+        const SeqDesc d = bd[i];
+        const uint32_t ml = d.w & 0xFFFFFFu;
+        uint32_t found = IX_NOT_DIRECT;
+        if (ml != 0 && !(d.w >> 31)) {
+            const uint32_t off = (d.x >> 24) | ((d.y >> 24) << 8), dm = d.z + (d.y & 0xFFFFFFu);
+            if (off <= dm && ml <= off) {                       // (overlapping matches replicate their own output: never direct)
+                uint32_t s0 = dm - off, hi = i;
+                for (uint32_t hop = 0; hop < IXR_HOPS; hop++) {
+                    uint32_t lo = 0;                            // last sequence that starts at or before s0
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi + 1) >> 1;
+                        if (bd[mid].z <= s0) lo = mid; else hi = mid - 1;
+                    }
+                    const SeqDesc dj = bd[lo];
+                    const uint32_t opj = dj.z, litj = dj.y & 0xFFFFFFu, mlj = dj.w & 0xFFFFFFu, dmj = opj + litj;
+                    const uint32_t fj = (dj.x >> 24) | ((dj.y >> 24) << 8);
+                    if (s0 < opj) break;
+                    if ((uint64_t)s0 + ml <= dmj) { found = (dj.x & 0xFFFFFFu) + (s0 - opj); break; }             // in its literal run
+                    if (s0 < dmj || (uint64_t)s0 + ml > (uint64_t)dmj + mlj) break;                                // straddles
+                    if (dj.w >> 31) { found = (fj | (((dj.w >> 24) & 0x7Fu) << 16)) + (s0 - dmj); break; }         // in a direct match
+                    if (fj == 0 || fj > dmj || mlj > fj) break;                                                    // in a run-length match
+                    s0 -= fj; hi = lo;                                                                             // in a plain match: follow it
+                }
+                if (found >= (1u << 23)) found = IX_NOT_DIRECT;
+            }
+            if (count_it) atomicAdd(flags + (found != IX_NOT_DIRECT ? 5 : 6), 1u);
+        } else if (count_it && ml) atomicAdd(flags + 4, 1u);
+        dsrc[blk.seq_base + i] = found;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One workgroup per block: the fused decoder's copier waves (decode_fused.cuh), fed from the descriptor array instead of
+// by a parser wave.
+template <class C>
+__global__ __launch_bounds__(64 * C::WAVES, 8) void k_copy_indexed(const uint8_t* __restrict__ frame, uint8_t* dst, BlockOut* __restrict__ table,
+                                                                   const ResultRec* __restrict__ res, uint32_t n_max, void* __restrict__ ix,
+                                                                   const SeqDesc* __restrict__ desc, const uint32_t* __restrict__ dsrc, const uint32_t* __restrict__ flags,
+                                                                   unsigned long long* prof)
+{
+    __shared__ FzShared<C> sh;
+    if (res->status != ST_OK || *flags) return;                              // index unusable: the generic kernel launched behind does the work
+    const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    if (b >= n) return;
+    const BlockOut e = table[b];
+    const uint32_t csz = e.word & 0x7FFFFFFFu;
+    int32_t got;
+    if (e.word >> 31) {                                                      // stored block: all waves copy a slice
+        got = -2;
+        if (csz <= e.dst_size) {
+            const uint32_t per = (((csz + C::WAVES - 1) / C::WAVES) + 15) & ~15u;
+            const uint32_t a = (tid >> 6) * per;
+            if (a < csz) wave_copy_disjoint(dst + e.dst_off + a, frame + e.src_off + a, (csz - a < per) ? csz - a : per);
+            got = (int32_t)csz;
+        }
+    } else {
+        const IxBlock blk = ix_blocks(ix)[b];
+        got = fz_decode_block<C, true>(sh, frame + e.src_off, csz, dst + e.dst_off, e.dst_size, 0, frame, prof, desc + blk.seq_base, blk.nseq,
+                                       dsrc ? dsrc + blk.seq_base : nullptr);
+    }
+    if (tid == 0) table[b].dst_size = (uint32_t)got;
+}
+
+}  // namespace lz4f

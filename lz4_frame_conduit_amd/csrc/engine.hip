@@ -157,7 +157,7 @@ extern "C" __attribute__((visibility("default"))) int lz4f_mi355x_debug_prof(uns
 }
 
 size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst, uint64_t dst_cap,
-                                           lz4f_mi355x_result* d_res, lz4f_mi355x_block* d_table)
+                                           lz4f_mi355x_result* d_res, lz4f_mi355x_block* d_table, void* d_index)
 {
     HIP_TRY(hipSetDevice(device));
     hipStream_t st = (hipStream_t)stream;
@@ -195,6 +195,8 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     tick(1, false);
     hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, g, (ChunkInfo*)info.p, (BlockOut*)d_table, (uint32_t*)blk_bytes.p,
                        d_dst, dst_cap, (ResultRec*)d_res);
+    if (d_index)                                  // sequence index for the indexed decoder (entry points per 128 KiB chunk)
+        hipLaunchKernelGGL(k_build_index, dim3(1), dim3(1024), 0, st, g, (const ChunkInfo*)info.p, (const BlockOut*)d_table, (const ResultRec*)d_res, d_index);
     tick(1, true);
     if (g.n_chunks) {
         tick(2, false);
@@ -253,6 +255,45 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         // small independent blocks: one wave per block ('1')
         char mode = (j.linked || j.block_size >= (256u << 10)) ? 'f' : '1';
         if (const char* dv = getenv("LZ4F_MI355X_DECODE")) mode = dv[0];
+        bool indexed = false;
+        if (mode == 'f' && j.d_index && !j.linked && !getenv("LZ4F_MI355X_NO_INDEX")) {
+            // descriptors from the compressor's sequence index: a lane per entry parses, a workgroup per block copies out of an
+            // LDS window.  The index header (16 bytes) is read back to size the descriptor workspace: the one host sync here.
+            IxHeader hd; memset(&hd, 0, sizeof(hd));
+            HIP_TRY(hipMemcpyAsync(&hd, j.d_index, sizeof(hd), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const uint32_t cpb = j.block_size / pick_chunk_size(j.block_size);
+            if (hd.magic == IX_MAGIC && hd.n_blocks == n_max && hd.chunks_per_block == cpb) {
+                const size_t dsrc_at = ((size_t)hd.total_seqs + 64) * sizeof(SeqDesc);
+                if (desc.ensure(dsrc_at + ((size_t)hd.total_seqs + 64) * 4) || seqcnt.ensure(256)) return make_err(LZ4F_ERROR_allocation_failed);
+                HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 32, st));
+                const uint64_t n_entries = (uint64_t)n_max * cpb;
+                unsigned long long* iprof = (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr);
+                tick(8, false);
+                hipLaunchKernelGGL(k_parse_indexed, dim3((uint32_t)((n_entries + 255) / 256)), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap,
+                                   (const BlockOut*)tbl, j.d_index, n_max, cpb, (SeqDesc*)desc.p, (uint64_t)hd.total_seqs, (uint32_t*)seqcnt.p);
+                uint32_t* dsrc = (uint32_t*)((uint8_t*)desc.p + dsrc_at);
+                if (getenv("LZ4F_MI355X_NO_RESOLVE")) dsrc = nullptr;
+                else
+                    hipLaunchKernelGGL(k_resolve_direct, dim3(IXR_WGS, n_max), dim3(256), 0, st, j.d_index, (const ResultRec*)d_res, n_max, (const SeqDesc*)desc.p,
+                                       dsrc, (uint64_t)hd.total_seqs, (uint32_t*)seqcnt.p, iprof ? 1u : 0u);
+                if (iprof) {                                                   // developer aid: how many matches are direct
+                    uint32_t c[8];
+                    if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(c, seqcnt.p, 32, hipMemcpyDeviceToHost) == hipSuccess)
+                        fprintf(stderr, "indexed: flags %u, matches direct after parse %u, resolved %u, left to the chain %u\n", c[0], c[4], c[5], c[6]);
+                }
+                tick(8, true);
+                tick(9, false);
+                if (j.block_size <= (1u << 20))
+                    hipLaunchKernelGGL(k_copy_indexed<FzCfg<4>>, dim3(n_max), dim3(64 * 4), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_max,
+                                       j.d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (const uint32_t*)seqcnt.p, iprof);
+                else
+                    hipLaunchKernelGGL(k_copy_indexed<FzCfg<8>>, dim3(n_max), dim3(64 * 8), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_max,
+                                       j.d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (const uint32_t*)seqcnt.p, iprof);
+                tick(9, true);
+                indexed = true;
+            }
+        }
         if (mode == 'f') {
             unsigned long long* prof = (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr);
             // more blocks than the machine has 8-wave workgroup slots: the 4-wave shape keeps twice as many in flight
@@ -260,7 +301,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             // a linked frame is one chain: one workgroup with the 64 KiB window in LDS; frames with short (flushed) blocks
             // set the flag and are decoded by the generic kernel launched right behind (it returns at once otherwise)
             const bool windowed = j.linked && j.dst_cap < 0xFFF00000ull && !getenv("LZ4F_MI355X_NO_WINDOW");
-            const uint32_t* only_if = nullptr;
+            const uint32_t* only_if = indexed ? (const uint32_t*)seqcnt.p : nullptr;      // behind the indexed kernels the generic one only runs if they gave up
             if (windowed) {
                 if (seqcnt.ensure(256)) return make_err(LZ4F_ERROR_allocation_failed);
                 hipLaunchKernelGGL(k_decode_linked, dim3(1), dim3(64 * LK_WAVES), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
@@ -544,6 +585,47 @@ size_t lz4f_mi355x_dev_compressFrame(lz4f_mi355x_engine* e, void* d_dst, size_t 
     j.linked = p.frameInfo.blockMode == LZ4F_blockLinked; j.block_checksum = p.frameInfo.blockChecksumFlag != 0; j.endmark = true;
     j.header_size = (uint32_t)write_frame_header(j.header, p);
     return e->launch_compress(j, (uint8_t*)d_dst, dstCapacity, d_result, d_table);
+}
+
+size_t lz4f_mi355x_dev_index_size(size_t srcSize, const LZ4F_preferences_t* prefs)
+{
+    size_t bs = block_size_of(prefs ? prefs->frameInfo.blockSizeID : 0);
+    if (!bs) bs = 65536;
+    const uint32_t ch = pick_chunk_size((uint32_t)bs);
+    return ix_bytes((uint32_t)((srcSize + bs - 1) / bs), (uint32_t)(bs / ch)) + 64;
+}
+
+size_t lz4f_mi355x_dev_compressFrameIndexed(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize,
+                                            const LZ4F_preferences_t* prefs, lz4f_mi355x_result* d_result, lz4f_mi355x_block* d_table, void* d_index)
+{
+    if (!e || !d_table || !d_result) return make_err(LZ4F_ERROR_GENERIC);
+    LZ4F_preferences_t p; memset(&p, 0, sizeof(p));
+    if (prefs) p = *prefs;
+    if (p.frameInfo.blockSizeID == 0) p.frameInfo.blockSizeID = LZ4F_max64KB;
+    const size_t bs = block_size_of(p.frameInfo.blockSizeID);
+    if (!bs) return make_err(LZ4F_ERROR_maxBlockSize_invalid);
+    if (p.frameInfo.contentChecksumFlag) { set_last_error("content checksum is host-only (serial XXH32): use lz4f_mi355x_compressFrame"); return make_err(LZ4F_ERROR_contentChecksumFlag_invalid); }
+    if (p.compressionLevel > 2) { set_last_error("only the fast encoder (level <= 2) exists"); return make_err(LZ4F_ERROR_compressionLevel_invalid); }
+    if (p.frameInfo.contentSize && p.frameInfo.contentSize != srcSize) return make_err(LZ4F_ERROR_frameSize_wrong);
+    lz4f_mi355x_engine::CompressJob j; memset(&j, 0, sizeof(j));
+    j.d_src = (const uint8_t*)d_src; j.src_size = srcSize; j.first_off = 0; j.block_size = (uint32_t)bs;
+    j.linked = p.frameInfo.blockMode == LZ4F_blockLinked; j.block_checksum = p.frameInfo.blockChecksumFlag != 0; j.endmark = true;
+    j.header_size = (uint32_t)write_frame_header(j.header, p);
+    return e->launch_compress(j, (uint8_t*)d_dst, dstCapacity, d_result, d_table, d_index);
+}
+
+size_t lz4f_mi355x_dev_decompressBlocksIndexed(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_frame, size_t frameCapacity,
+                                               const lz4f_mi355x_block* d_table, uint32_t n_blocks, const LZ4F_frameInfo_t* info,
+                                               const void* d_index, lz4f_mi355x_result* d_result)
+{
+    if (!e || !d_table || !info) return make_err(LZ4F_ERROR_GENERIC);
+    const size_t bs = block_size_of(info->blockSizeID);
+    if (!bs) return make_err(LZ4F_ERROR_maxBlockSize_invalid);
+    lz4f_mi355x_engine::DecompressJob j; memset(&j, 0, sizeof(j));
+    j.d_frame = (const uint8_t*)d_frame; j.frame_cap = frameCapacity; j.d_dst = (uint8_t*)d_dst; j.dst_cap = dstCapacity; j.hist0 = 0;
+    j.block_size = (uint32_t)bs; j.linked = info->blockMode == LZ4F_blockLinked; j.block_checksum = info->blockChecksumFlag != 0;
+    j.d_table = d_table; j.n_blocks = n_blocks; j.max_blocks = n_blocks; j.d_index = (void*)d_index;
+    return e->launch_decompress(j, d_result);
 }
 
 size_t lz4f_mi355x_dev_decompressFrame(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_frame, size_t frameCapacity,

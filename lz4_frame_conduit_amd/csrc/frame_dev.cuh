@@ -11,6 +11,7 @@
 #include "decode_fused.cuh"
 #include "decode_linked.cuh"
 #include "encode.cuh"
+#include "decode_indexed.cuh"
 
 namespace lz4f {
 

@@ -64,13 +64,25 @@ class Engine:
     def frame_bound(self, n: int, prefs: Preferences) -> int:
         return _chk(self.L, self.L.lz4f_mi355x_compressFrameBound(n, ctypes.byref(prefs)))
 
-    def compress_async(self, src: torch.Tensor, dst: torch.Tensor, prefs: Preferences, table: "torch.Tensor | None" = None):
-        """Enqueue src -> one frame in dst.  Returns nothing; call result() after a sync."""
+    def compress_async(self, src: torch.Tensor, dst: torch.Tensor, prefs: Preferences, table: "torch.Tensor | None" = None,
+                       index: "torch.Tensor | None" = None):
+        """Enqueue src -> one frame in dst.  Returns nothing; call result() after a sync.
+        With `index` (new_index) the compressor also leaves its sequence index there for decompress_blocks_async."""
         assert src.dtype == torch.uint8 and dst.dtype == torch.uint8 and src.is_cuda and dst.is_cuda
+        if index is not None:
+            assert table is not None and index.numel() >= self.index_size(src.numel(), prefs)
+            _chk(self.L, self.L.lz4f_mi355x_dev_compressFrameIndexed(self.h, dst.data_ptr(), dst.numel(), src.data_ptr(), src.numel(), ctypes.byref(prefs),
+                                                                    self._res.data_ptr(), table.data_ptr(), index.data_ptr()))
+            return
         _chk(self.L, self.L.lz4f_mi355x_dev_compressFrame(self.h, dst.data_ptr(), dst.numel(), src.data_ptr(), src.numel(), ctypes.byref(prefs),
                                                          self._res.data_ptr(), table.data_ptr() if table is not None else None))
 
-    def decompress_blocks_async(self, frame: torch.Tensor, frame_len: int, dst: torch.Tensor, table: torch.Tensor, n_blocks: int, info: FrameInfo):
+    def decompress_blocks_async(self, frame: torch.Tensor, frame_len: int, dst: torch.Tensor, table: torch.Tensor, n_blocks: int, info: FrameInfo,
+                                index: "torch.Tensor | None" = None):
+        if index is not None:
+            _chk(self.L, self.L.lz4f_mi355x_dev_decompressBlocksIndexed(self.h, dst.data_ptr(), dst.numel(), frame.data_ptr(), frame_len, table.data_ptr(),
+                                                                       n_blocks, ctypes.byref(info), index.data_ptr(), self._res.data_ptr()))
+            return
         _chk(self.L, self.L.lz4f_mi355x_dev_decompressBlocks(self.h, dst.data_ptr(), dst.numel(), frame.data_ptr(), frame_len, table.data_ptr(),
                                                             n_blocks, ctypes.byref(info), self._res.data_ptr()))
 
@@ -86,6 +98,12 @@ class Engine:
 
     def new_table(self, n_blocks: int) -> torch.Tensor:
         return torch.zeros((n_blocks + 1) * ctypes.sizeof(Block), dtype=torch.uint8, device="cuda:%d" % self.device)
+
+    def index_size(self, n: int, prefs: Preferences) -> int:
+        return int(self.L.lz4f_mi355x_dev_index_size(n, ctypes.byref(prefs)))
+
+    def new_index(self, n: int, prefs: Preferences) -> torch.Tensor:
+        return torch.zeros(self.index_size(n, prefs), dtype=torch.uint8, device="cuda:%d" % self.device)
 
     def xxh32(self, base: torch.Tensor, offs: np.ndarray, lens: np.ndarray) -> np.ndarray:
         dev = "cuda:%d" % self.device
