@@ -39,6 +39,7 @@ template <class C>
 struct alignas(16) FzShared {
     uint4    ring[C::RING][64];
     uint8_t  stage[2][C::STAGE + FZ_OVER];
+    uint4    gt[C::WAVES - 1][2][64];           // per copier wave: the gather tables of its slot (see the literal phase)
     uint32_t produced;                          // slots the parser has published
     uint32_t total_slots;                       // valid once `finished` is set
     uint32_t last_count;                        // descriptors in the last slot
@@ -309,53 +310,108 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
         const uint32_t vmsrc = voff | (((d.w >> 24) & 0x7Fu) << 16);
         const uint64_t direct_m = FED ? __ballot(vdirect) : 0ull;
 
-        // ---- (1) literals: no dependencies.  Software pipeline, two jobs per stage, two stages: the loads of the next two
-        // pieces are issued before the stores of the current two, with hand-counted waits (see common.cuh).
+        // ---- (1) literal runs (and direct matches): no dependencies.  A gather with no scalar work per run -- a CU has ONE
+        // scalar unit, and a copy loop that spends ~100 scalar instructions per run is bound by it.  The runs of the slot are
+        // cut into 16-byte units; a prefix sum over the lanes gives every run its first unit; lane l of round r takes unit
+        // 64 r + l, finds the run it belongs to with a six-step binary search over the 64 prefix values (LDS), and moves its
+        // 16 bytes (the last unit of a run overlaps the one before).  Runs shorter than 16 bytes go the same way byte by byte.
         {
-            uint32_t k = 0, off = 0, part = 0;                           // scalar iterator over (descriptor, literal run / direct match, 1 KiB round)
-            auto next_job = [&]() -> CopyJob {
-                for (;;) {
-                    if (k >= count) return CopyJob{safe, out, 0};
-                    uint32_t len = __builtin_amdgcn_readlane(vlen, k);
-                    const uint8_t* sp = in + __builtin_amdgcn_readlane(vsrc, k);
-                    uint8_t* dp = out + __builtin_amdgcn_readlane(vdst, k);
-                    if (FED && part) { dp += len; len = __builtin_amdgcn_readlane(vml, k); sp = in + __builtin_amdgcn_readlane(vmsrc, k); }
-                    auto advance = [&]() { off = 0; if (FED && part == 0 && ((direct_m >> k) & 1)) part = 1; else { part = 0; k++; } };
-                    if (len < 16) {                                      // tiny run: bytewise, right now
-                        if (lane < len) dp[lane] = sp[lane];
-                        advance(); continue;
-                    }
-                    uint32_t o = off, n = len - off;
-                    if (n > 1024) n = 1024;
-                    if (n < 16) { o = len - 16; n = 16; }                // ragged end of a long run: overlap backwards
-                    off += 1024;
-                    if (off >= len) advance();
-                    return CopyJob{sp + o, dp + o, n};
-                }
+            uint4* T0 = sh.gt[cw][0];
+            uint4* T1 = sh.gt[cw][1];
+            const uint32_t L = lane < count ? vlen : 0u, M = vdirect ? vml : 0u;
+            auto scan = [&](uint32_t v, uint32_t& total) -> uint32_t {              // exclusive prefix sum over the wave
+                uint32_t incl = v;
+#pragma unroll
+                for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t t = __shfl_up(incl, sft); if ((int)lane >= sft) incl += t; }
+                total = __builtin_amdgcn_readlane(incl, 63);
+                return incl - v;
             };
-            // ping-pong: two register sets of NL jobs; no register moves between stages.  Fed descriptors leave the copiers as
-            // the only limit of a block, and then the bytes in flight per wave are what counts: twice the depth
-            constexpr int NL = FED ? FZ_FED_DEPTH : 2;
-            CopyJob A[NL], B[NL];
-            Piece PA[NL], PB[NL];
+            auto find = [&](uint32_t u) -> uint32_t {                               // last run whose first unit is <= u
+                uint32_t j = 0;
 #pragma unroll
-            for (int i = 0; i < NL; i++) A[i] = next_job();
+                for (uint32_t step = 32; step; step >>= 1) { const uint32_t c = j + step; if (T0[c].x <= u) j = c; }
+                return j;
+            };
+            // pass A: runs of >= 16 bytes
+            uint32_t total;
+            {
+                const uint32_t uL = L >= 16 ? (L + 15) >> 4 : 0u, uM = M >= 16 ? (M + 15) >> 4 : 0u;
+                const uint32_t P = scan(uL + uM, total);
+                if (total) {
+                    T0[lane] = uint4{P, uL, L, M};
+                    T1[lane] = uint4{vsrc, vmsrc, vdst, 0u};
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                }
+            }
+            if (total) {
+                auto ld = [&](Piece& pc, uint32_t u, uint32_t& dof, bool& act) {
+                    const uint32_t j = find(u);
+                    const uint4 e0 = T0[j], e1 = T1[j];
+                    uint32_t r = u - e0.x;
+                    const bool isM = r >= e0.y;
+                    r -= isM ? e0.y : 0u;
+                    const uint32_t len = isM ? e0.w : e0.z;
+                    uint32_t off = r * 16u;
+                    off = (off + 16u > len) ? len - 16u : off;
+                    act = u < total;
+                    dof = e1.z + (isM ? e0.z : 0u) + off;
+                    const uint8_t* a = act ? in + ((isM ? e1.y : e1.x) + off) : safe;
+                    const v4u_ua t = *(const v4u_ua*)a;
+                    pc.a = t.a; pc.b = t.b; pc.c = t.c; pc.d = t.d;
+                };
+                // fed descriptors: what is written here is not read again (matches come out of the payload), so the stores
+                // bypass the caches and leave them to the payload, which is read twice
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                typedef u32x4 u32x4_ua __attribute__((aligned(1)));
+                auto st = [&](const Piece& pc, uint32_t dof, bool act) {
+                    if (!act) return;
+                    if (FED) __builtin_nontemporal_store(u32x4{pc.a, pc.b, pc.c, pc.d}, (u32x4_ua*)(out + dof));
+                    else *(v4u_ua*)(out + dof) = v4u_ua{pc.a, pc.b, pc.c, pc.d};
+                };
+                Piece a0, b0;                                                   // ping-pong, one round each: a load is in flight while the previous round is stored
+                uint32_t da0, db0;
+                bool xa0, xb0;
+                uint32_t base = 0;
+                ld(a0, base + lane, da0, xa0); base += 64;
+                for (;;) {
+                    const bool more_b = base < total;
+                    ld(b0, base + lane, db0, xb0); base += 64;
+                    st(a0, da0, xa0);
+                    if (!more_b) break;
+                    const bool more_a = base < total;
+                    ld(a0, base + lane, da0, xa0); base += 64;
+                    st(b0, db0, xb0);
+                    if (!more_a) break;
+                }
+            }
+            // pass B: runs of 1..15 bytes, a lane per byte
+            uint32_t total_b;
+            {
+                const uint32_t bL = L < 16 ? L : 0u, bM = M < 16 ? M : 0u;
+                const uint32_t P = scan(bL + bM, total_b);
+                if (total_b) {
+                    T0[lane] = uint4{P, bL, L, M};
+                    T1[lane] = uint4{vsrc, vmsrc, vdst, 0u};
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+                }
+            }
+            for (uint32_t base = 0; base < total_b; base += 128) {
+                uint8_t v[2]; uint32_t dof[2]; bool act[2];
 #pragma unroll
-            for (int i = 0; i < NL; i++) job_load(PA[i], A[i], safe);
-            while (A[0].n) {
+                for (int i = 0; i < 2; i++) {
+                    const uint32_t u = base + 64 * i + lane;
+                    const uint32_t j = find(u);
+                    const uint4 e0 = T0[j], e1 = T1[j];
+                    uint32_t r = u - e0.x;
+                    const bool isM = r >= e0.y;
+                    r -= isM ? e0.y : 0u;
+                    act[i] = u < total_b;
+                    dof[i] = e1.z + (isM ? e0.z : 0u) + r;
+                    const uint8_t* a = act[i] ? in + ((isM ? e1.y : e1.x) + r) : safe;
+                    v[i] = *a;
+                }
 #pragma unroll
-                for (int i = 0; i < NL; i++) B[i] = next_job();
-#pragma unroll
-                for (int i = 0; i < NL; i++) job_load(PB[i], B[i], safe);
-#pragma unroll
-                for (int i = 0; i < NL; i++) job_store(A[i], PA[i]);
-                if (B[0].n == 0) break;
-#pragma unroll
-                for (int i = 0; i < NL; i++) A[i] = next_job();
-#pragma unroll
-                for (int i = 0; i < NL; i++) job_load(PA[i], A[i], safe);
-#pragma unroll
-                for (int i = 0; i < NL; i++) job_store(B[i], PB[i]);
+                for (int i = 0; i < 2; i++) if (act[i]) out[dof[i]] = v[i];
             }
         }
         // ---- (2) matches, in stream order, after every earlier slot's matches ----

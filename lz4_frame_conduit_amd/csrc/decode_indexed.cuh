@@ -37,95 +37,37 @@ __device__ __forceinline__ uint64_t pt_load8(const uint8_t* __restrict__ in, uin
     return v;
 }
 
-constexpr uint32_t IX_MAGIC = 0x3158494Cu;                     // "LIX1"
-struct IxHeader { uint32_t magic, n_blocks, chunks_per_block, total_seqs; };
-struct IxBlock  { uint32_t seq_base, nseq; };                  // first descriptor of the block; 0 sequences: stored block / not indexed
-struct IxEntry  { uint32_t in_off, out_pos, seq_off, nseq; };  // per chunk; nseq == 0: no entry
-__host__ __device__ inline size_t ix_bytes(uint32_t n_blocks, uint32_t chunks_per_block)
-{
-    return sizeof(IxHeader) + (size_t)n_blocks * sizeof(IxBlock) + (size_t)n_blocks * chunks_per_block * sizeof(IxEntry);
-}
-__device__ __forceinline__ IxBlock* ix_blocks(void* ix) { return (IxBlock*)((uint8_t*)ix + sizeof(IxHeader)); }
-__device__ __forceinline__ IxEntry* ix_entries(void* ix, uint32_t n_blocks) { return (IxEntry*)((uint8_t*)ix + sizeof(IxHeader) + (size_t)n_blocks * sizeof(IxBlock)); }
-
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_build_index(EncGeom g, const ChunkInfo* __restrict__ info, const BlockOut* __restrict__ table,
-                                                      const ResultRec* __restrict__ res, void* __restrict__ ix)
-{
-    __shared__ uint32_t s_part[1024];
-    __shared__ uint32_t s_carry;
-    const uint32_t t = threadIdx.x;
-    IxHeader* hd = (IxHeader*)ix;
-    IxBlock* blocks = ix_blocks(ix);
-    IxEntry* entries = ix_entries(ix, g.n_blocks);
-    const bool usable = res->status == ST_OK && !g.linked;
-    // 1) per block: entries of its chunks, sequence count
-    for (uint32_t b = t; b < g.n_blocks; b += 1024) {
-        const BlockOut e = table[b];
-        const ChunkInfo* ci = info + (uint64_t)b * g.chunks_per_block;
-        IxEntry* en = entries + (uint64_t)b * g.chunks_per_block;
-        const uint32_t blen = e.dst_size;
-        const uint32_t nch = (blen + g.chunk_size - 1) / g.chunk_size;
-        uint32_t nseq = 0, last = 0xFFFFFFFFu;
-        for (uint32_t c = 0; c < g.chunks_per_block; c++) {
-            IxEntry x{0, 0, 0, 0};
-            if (usable && !(e.word >> 31) && c < nch && ci[c].nrec) {
-                x.in_off = (uint32_t)(ci[c].out_off - e.src_off);          // the chunk's first token (pass E2 starts writing there)
-                x.out_pos = c * g.chunk_size - ci[c].carry_in;             // its literal run starts with the literals carried in
-                x.seq_off = nseq; x.nseq = ci[c].nrec;
-                nseq += ci[c].nrec; last = c;
-            }
-            en[c] = x;
-        }
-        if (last != 0xFFFFFFFFu) { en[last].nseq += 1; nseq += 1; }        // the block's final literal-only sequence
-        blocks[b].nseq = nseq;
-    }
-    __syncthreads();
-    // 2) exclusive scan of the per-block counts in tiles of 1024
-    if (t == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < g.n_blocks; base += 1024) {
-        const uint32_t b = base + t;
-        const uint32_t v = (b < g.n_blocks) ? blocks[b].nseq : 0;
-        s_part[t] = v;
-        __syncthreads();
-        for (uint32_t off = 1; off < 1024; off <<= 1) {
-            const uint32_t add = (t >= off) ? s_part[t - off] : 0;
-            __syncthreads();
-            s_part[t] += add;
-            __syncthreads();
-        }
-        if (b < g.n_blocks) blocks[b].seq_base = s_carry + s_part[t] - v;
-        __syncthreads();
-        if (t == 1023) s_carry += s_part[1023];
-        __syncthreads();
-    }
-    if (t == 0) { hd->magic = usable ? IX_MAGIC : 0u; hd->n_blocks = g.n_blocks; hd->chunks_per_block = g.chunks_per_block; hd->total_seqs = s_carry; }
-}
-
-// ------------------------------------------------------------------------------------------------
-// One lane per index entry.  Input-side rules only (the copy kernel checks the ones that need output positions).
-// `flags[0]` is set when anything disagrees with the index: the caller then falls back to the generic decoder.
+// k_parse_indexed, one lane per index entry.  (The index structures and k_build_index live in encode.cuh: pass E2 writes the entries.)
+// Input-side rules only (the feeder wave checks the ones that need output positions).  `flags[0]` is set when anything
+// disagrees with the index: the caller then falls back to the generic decoder.  Every entry must end exactly where the next
+// one starts and the first one of a block at payload byte 0, so the descriptors are a complete parse of the payload itself:
+// a wrong index can make the call fall back, never change the bytes that come out.
 __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
-                                                       void* __restrict__ ix, uint32_t n_blocks, uint32_t chunks_per_block,
+                                                       const void* __restrict__ ix, uint32_t n_blocks, uint32_t n_entries,
                                                        SeqDesc* __restrict__ desc, uint64_t desc_cap, uint32_t* __restrict__ flags)
 {
-    const uint64_t cidx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (cidx >= (uint64_t)n_blocks * chunks_per_block) return;
-    const uint32_t b = (uint32_t)(cidx / chunks_per_block), c = (uint32_t)(cidx % chunks_per_block);
-    const IxEntry* en = ix_entries(ix, n_blocks) + (uint64_t)b * chunks_per_block;
-    const IxEntry me = en[c];
-    if (me.nseq == 0) return;
-    const IxBlock blk = ix_blocks(ix)[b];
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const IxBlock* blocks = ix_blocks(ix);
+    if (gid < n_blocks) {                                                       // a compressed block without entries cannot be decoded from the index
+        const IxBlock bk = blocks[gid];
+        if (!(table[gid].word >> 31) && (bk.nentries == 0 || bk.nseq == 0 || (uint64_t)bk.entry_base + bk.nentries > n_entries)) atomicOr(flags, 1u);
+    }
+    if (gid >= n_entries) return;
+    const IxEntry* entries = ix_entries(ix, n_blocks);
+    const IxEntry me = entries[gid];
+    const uint32_t b = me.nseq_blk >> 8, my_nseq = me.nseq_blk & 0xFFu;
+    if (b >= n_blocks) { atomicOr(flags, 1u); return; }
+    const IxBlock blk = blocks[b];
     const BlockOut e = table[b];
     const uint32_t csize = e.word & 0x7FFFFFFFu;
-    bool bad = (e.word >> 31) != 0 || e.src_off + csize > frame_cap || me.in_off >= csize || (uint64_t)blk.seq_base + me.seq_off + me.nseq > desc_cap;
-    // where the next entry of this block starts (or the payload ends)
-    uint32_t stop = csize; bool is_tail = true, is_head = true;
-    for (uint32_t k = c + 1; k < chunks_per_block; k++) if (en[k].nseq) { stop = en[k].in_off; is_tail = false; break; }
-    for (uint32_t k = 0; k < c; k++) if (en[k].nseq) { is_head = false; break; }
-    if (is_head && (me.in_off != 0 || me.out_pos != 0 || me.seq_off != 0)) bad = true;      // the entries must cover the payload from its first byte
+    bool bad = (e.word >> 31) != 0 || e.src_off + csize > frame_cap || me.in_off >= csize || my_nseq == 0 || gid < blk.entry_base ||
+               gid >= blk.entry_base + blk.nentries || (uint64_t)me.seq_off + my_nseq > blk.nseq || (uint64_t)blk.seq_base + blk.nseq > desc_cap;
     if (bad) { atomicOr(flags, 1u); return; }
+    const bool is_head = gid == blk.entry_base, is_tail = gid + 1 == blk.entry_base + blk.nentries;
+    const uint32_t stop = is_tail ? csize : entries[gid + 1].in_off;           // where the next entry of this block starts (or the payload ends)
+    if (is_head && (me.in_off != 0 || me.out_pos != 0 || me.seq_off != 0)) bad = true;      // the entries must cover the payload from its first byte
+    if (!is_tail && entries[gid + 1].seq_off != me.seq_off + my_nseq) bad = true;
+    if (is_tail && me.seq_off + my_nseq != blk.nseq) bad = true;
     const uint8_t* in = frame + e.src_off;
     const uint64_t readable = frame_cap - e.src_off;
     SeqDesc* out = desc + blk.seq_base + me.seq_off;
@@ -134,7 +76,7 @@ __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict
     // range): a match that lies inside one is DIRECT -- a plain copy out of the payload that needs no earlier output
     uint32_t r0o = 0, r0n = 0, r0p = 0, r1o = 0, r1n = 0, r1p = 0, r2o = 0, r2n = 0, r2p = 0, r3o = 0, r3n = 0, r3p = 0;
     auto remember = [&](uint32_t o, uint32_t n, uint32_t pp) { r3o = r2o; r3n = r2n; r3p = r2p; r2o = r1o; r2n = r1n; r2p = r1p; r1o = r0o; r1n = r0n; r1p = r0p; r0o = o; r0n = n; r0p = pp; };
-    for (uint32_t i = 0; i < me.nseq; i++) {
+    for (uint32_t i = 0; i < my_nseq && !bad; i++) {
         if (pos >= csize) { bad = true; break; }
         const uint64_t w = pt_load8(in, pos, readable);
         const uint32_t token = (uint32_t)w & 0xFF;
@@ -149,7 +91,7 @@ __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict
         const uint32_t in_left = csize - p;
         uint32_t mlen = 0, off = 0;
         if (lit + 8 > in_left) {                                               // the block's last sequence
-            if (lit != in_left || !is_tail || i + 1 != me.nseq) { bad = true; break; }
+            if (lit != in_left || !is_tail || i + 1 != my_nseq) { bad = true; break; }
             pos = csize;
         } else {
             const uint32_t q = p + lit;
@@ -188,7 +130,6 @@ __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict
     if (!bad && pos != stop) bad = true;                                       // must end exactly where the next entry starts
     if (bad) atomicOr(flags, 1u);
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // One lane per sequence: where in the PAYLOAD do the bytes of my match come from?  The lane looks up the sequence that

@@ -374,6 +374,86 @@ __global__ __launch_bounds__(1024) void k_layout(EncGeom g, ChunkInfo* __restric
     if (!fits) for (uint32_t c = t; c < g.n_chunks; c += 1024) info[c].flags |= 4u;   // tell pass E2 to do nothing
 }
 
+// ------------------------------- sequence index (optional) -------------------------------------
+// A side table for this library's own decoder (decode_indexed.cuh): an entry point into the block's payload every IX_STRIDE
+// sequences -- where the token sits, which output position the sequence starts at.  The frame does not change.
+//   k_build_index (after pass S)  per chunk: where its entries and sequences start within the block; per block: totals,
+//                                 exclusive scans over the blocks; the header
+//   pass E2                       writes the entries while it walks the records (it has both positions at hand)
+constexpr uint32_t IX_MAGIC = 0x3258494Cu;                     // "LIX2"
+constexpr uint32_t IX_STRIDE = 64;                             // sequences per entry
+struct IxHeader { uint32_t magic, n_blocks, chunks_per_block, total_seqs, total_entries, stride, pad0, pad1; };
+struct IxBlock  { uint32_t seq_base, nseq, entry_base, nentries; };    // nseq == 0: stored block / nothing to index
+struct IxChunk  { uint32_t ent_off, seq_off; };                // first entry / first sequence of the chunk within its block; ent_off bit 31: the block's final sequence follows this chunk's records
+struct IxEntry  { uint32_t in_off, out_pos, seq_off, nseq_blk; };      // payload offset, output position, first sequence (all within the block); sequences | block << 8
+__host__ __device__ inline uint32_t ix_max_entries_per_chunk(uint32_t chunk_size) { return (chunk_size / 4 + 1 + IX_STRIDE - 1) / IX_STRIDE + 1; }
+__host__ __device__ inline size_t ix_entries_at(uint32_t n_blocks, uint32_t chunks_per_block)
+{
+    return sizeof(IxHeader) + (size_t)n_blocks * sizeof(IxBlock) + (size_t)n_blocks * chunks_per_block * sizeof(IxChunk);
+}
+__host__ __device__ inline size_t ix_bytes(uint32_t n_blocks, uint32_t chunks_per_block, uint32_t chunk_size)
+{
+    return ix_entries_at(n_blocks, chunks_per_block) + (size_t)n_blocks * chunks_per_block * ix_max_entries_per_chunk(chunk_size) * sizeof(IxEntry);
+}
+__device__ __forceinline__ IxBlock* ix_blocks(void* ix) { return (IxBlock*)((uint8_t*)ix + sizeof(IxHeader)); }
+__device__ __forceinline__ const IxBlock* ix_blocks(const void* ix) { return (const IxBlock*)((const uint8_t*)ix + sizeof(IxHeader)); }
+__device__ __forceinline__ IxChunk* ix_chunks(void* ix, uint32_t n_blocks) { return (IxChunk*)((uint8_t*)ix + sizeof(IxHeader) + (size_t)n_blocks * sizeof(IxBlock)); }
+// (the decoder does not know the compressor's chunking: the entries start behind a table whose size the header gives)
+__device__ __forceinline__ IxEntry* ix_entries_w(void* ix, uint32_t n_blocks, uint32_t chunks_per_block) { return (IxEntry*)((uint8_t*)ix + ix_entries_at(n_blocks, chunks_per_block)); }
+__device__ __forceinline__ const IxEntry* ix_entries(const void* ix, uint32_t n_blocks)
+{
+    return (const IxEntry*)((const uint8_t*)ix + ix_entries_at(n_blocks, ((const IxHeader*)ix)->chunks_per_block));
+}
+
+__global__ __launch_bounds__(1024) void k_build_index(EncGeom g, const ChunkInfo* __restrict__ info, const BlockOut* __restrict__ table,
+                                                      const ResultRec* __restrict__ res, void* __restrict__ ix)
+{
+    __shared__ uint32_t s_a[1024], s_b[1024];
+    __shared__ uint32_t s_carry_a, s_carry_b;
+    const uint32_t t = threadIdx.x;
+    IxHeader* hd = (IxHeader*)ix;
+    IxBlock* blocks = ix_blocks(ix);
+    IxChunk* chunks = ix_chunks(ix, g.n_blocks);
+    const bool usable = res->status == ST_OK && !g.linked;
+    // 1) per block: its chunks in order
+    for (uint32_t b = t; b < g.n_blocks; b += 1024) {
+        const BlockOut e = table[b];
+        const ChunkInfo* ci = info + (uint64_t)b * g.chunks_per_block;
+        IxChunk* ck = chunks + (uint64_t)b * g.chunks_per_block;
+        const uint32_t nch = (e.dst_size + g.chunk_size - 1) / g.chunk_size;
+        uint32_t nseq = 0, nent = 0, last = 0xFFFFFFFFu;
+        for (uint32_t c = 0; c < g.chunks_per_block; c++) {
+            ck[c] = IxChunk{nent, nseq};
+            if (usable && !(e.word >> 31) && c < nch && ci[c].nrec) {
+                nseq += ci[c].nrec; nent += (ci[c].nrec + IX_STRIDE - 1) / IX_STRIDE; last = c;
+            }
+        }
+        if (last != 0xFFFFFFFFu) { ck[last].ent_off |= 0x80000000u; nseq += 1; }     // the block's final literal-only sequence
+        blocks[b].nseq = nseq; blocks[b].nentries = nent;
+    }
+    __syncthreads();
+    // 2) exclusive scans of both counts over the blocks, in tiles of 1024
+    if (t == 0) { s_carry_a = 0; s_carry_b = 0; }
+    __syncthreads();
+    for (uint32_t base = 0; base < g.n_blocks; base += 1024) {
+        const uint32_t b = base + t;
+        const uint32_t va = (b < g.n_blocks) ? blocks[b].nseq : 0, vb = (b < g.n_blocks) ? blocks[b].nentries : 0;
+        s_a[t] = va; s_b[t] = vb;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            const uint32_t aa = (t >= off) ? s_a[t - off] : 0, ab = (t >= off) ? s_b[t - off] : 0;
+            __syncthreads();
+            s_a[t] += aa; s_b[t] += ab;
+            __syncthreads();
+        }
+        if (b < g.n_blocks) { blocks[b].seq_base = s_carry_a + s_a[t] - va; blocks[b].entry_base = s_carry_b + s_b[t] - vb; }
+        __syncthreads();
+        if (t == 1023) { s_carry_a += s_a[1023]; s_carry_b += s_b[1023]; }
+        __syncthreads();
+    }
+    if (t == 0) *hd = IxHeader{usable ? IX_MAGIC : 0u, g.n_blocks, g.chunks_per_block, s_carry_a, s_carry_b, IX_STRIDE, 0u, 0u};
+}
+
 // ------------------------------- pass E2 -------------------------------------------------------
 __device__ __forceinline__ void emit_len_ext(uint8_t* p, uint32_t v /* value minus 15 */)
 {
@@ -385,7 +465,7 @@ __device__ __forceinline__ void emit_len_ext(uint8_t* p, uint32_t v /* value min
 template <int WAVES_PER_WG>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_emit(const uint8_t* __restrict__ src, EncGeom g,
                                                             const ChunkInfo* __restrict__ info, const uint64_t* __restrict__ recs,
-                                                            uint8_t* __restrict__ dst)
+                                                            uint8_t* __restrict__ dst, const BlockOut* __restrict__ table, void* __restrict__ ix)
 {
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t chunk = uni(blockIdx.x * WAVES_PER_WG + wave);
@@ -409,7 +489,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_emit(const uint8_t* __res
     }
     const uint64_t* rec = recs + (uint64_t)chunk * g.max_rec_per_chunk;
     const uint8_t* lp = src + (cs_abs - ci.carry_in);       // start of the pending literal run
+    // sequence index: an entry every IX_STRIDE records
+    IxEntry* ent = nullptr; uint32_t ent_seq0 = 0, ent_last = 0; const uint8_t* pay0 = nullptr;
+    if (ix && ((const IxHeader*)ix)->magic == IX_MAGIC && ci.nrec) {
+        const IxChunk ck = ix_chunks(ix, g.n_blocks)[chunk];
+        ent = ix_entries_w(ix, g.n_blocks, g.chunks_per_block) + ix_blocks(ix)[blk].entry_base + (ck.ent_off & 0x7FFFFFFFu);
+        ent_seq0 = ck.seq_off; ent_last = ck.ent_off >> 31;
+        pay0 = dst + table[blk].src_off;
+    }
     for (uint32_t r = 0; r < ci.nrec; r++) {
+        if (ent && (r % IX_STRIDE) == 0 && lane == 0) {
+            uint32_t ns = ci.nrec - r < IX_STRIDE ? ci.nrec - r : IX_STRIDE;
+            if (ent_last && r + IX_STRIDE >= ci.nrec) ns += 1;                 // the block's final sequence rides on its last entry
+            ent[r / IX_STRIDE] = IxEntry{(uint32_t)(o - pay0), (uint32_t)(lp - (src + bstart)), ent_seq0 + r, ns | (blk << 8)};
+        }
         const uint64_t x = rec[r];
         uint32_t lit = (uint32_t)(x & 0xFFFFFFu);
         const uint32_t mlen = (uint32_t)((x >> 24) & 0xFFFFFFu), off = (uint32_t)(x >> 48);

@@ -201,7 +201,7 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     if (g.n_chunks) {
         tick(2, false);
         hipLaunchKernelGGL((k_emit<W>), dim3((g.n_chunks + W - 1) / W), dim3(64 * W), 0, st, j.d_src, g, (const ChunkInfo*)info.p,
-                           (const uint64_t*)recs.p, d_dst);
+                           (const uint64_t*)recs.p, d_dst, (const BlockOut*)d_table, d_index);
         tick(2, true);
         if (j.block_checksum) {
             tick(3, false);
@@ -262,16 +262,18 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             IxHeader hd; memset(&hd, 0, sizeof(hd));
             HIP_TRY(hipMemcpyAsync(&hd, j.d_index, sizeof(hd), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            const uint32_t cpb = j.block_size / pick_chunk_size(j.block_size);
-            if (hd.magic == IX_MAGIC && hd.n_blocks == n_max && hd.chunks_per_block == cpb) {
+            const uint32_t chunk = pick_chunk_size(j.block_size), cpb = j.block_size / chunk;
+            if (hd.magic == IX_MAGIC && hd.n_blocks == n_max && hd.chunks_per_block == cpb && hd.stride == IX_STRIDE &&
+                hd.total_entries <= (uint64_t)n_max * cpb * ix_max_entries_per_chunk(chunk) && hd.total_seqs <= (uint64_t)hd.total_entries * (IX_STRIDE + 1)) {
                 const size_t dsrc_at = ((size_t)hd.total_seqs + 64) * sizeof(SeqDesc);
                 if (desc.ensure(dsrc_at + ((size_t)hd.total_seqs + 64) * 4) || seqcnt.ensure(256)) return make_err(LZ4F_ERROR_allocation_failed);
                 HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 32, st));
-                const uint64_t n_entries = (uint64_t)n_max * cpb;
+                const uint32_t n_entries = hd.total_entries;
+                const uint32_t n_lanes = n_entries > n_max ? n_entries : n_max;
                 unsigned long long* iprof = (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr);
                 tick(8, false);
-                hipLaunchKernelGGL(k_parse_indexed, dim3((uint32_t)((n_entries + 255) / 256)), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap,
-                                   (const BlockOut*)tbl, j.d_index, n_max, cpb, (SeqDesc*)desc.p, (uint64_t)hd.total_seqs, (uint32_t*)seqcnt.p);
+                hipLaunchKernelGGL(k_parse_indexed, dim3((n_lanes + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap,
+                                   (const BlockOut*)tbl, (const void*)j.d_index, n_max, n_entries, (SeqDesc*)desc.p, (uint64_t)hd.total_seqs, (uint32_t*)seqcnt.p);
                 uint32_t* dsrc = (uint32_t*)((uint8_t*)desc.p + dsrc_at);
                 if (getenv("LZ4F_MI355X_NO_RESOLVE")) dsrc = nullptr;
                 else
@@ -592,7 +594,7 @@ size_t lz4f_mi355x_dev_index_size(size_t srcSize, const LZ4F_preferences_t* pref
     size_t bs = block_size_of(prefs ? prefs->frameInfo.blockSizeID : 0);
     if (!bs) bs = 65536;
     const uint32_t ch = pick_chunk_size((uint32_t)bs);
-    return ix_bytes((uint32_t)((srcSize + bs - 1) / bs), (uint32_t)(bs / ch)) + 64;
+    return ix_bytes((uint32_t)((srcSize + bs - 1) / bs), (uint32_t)(bs / ch), ch) + 64;
 }
 
 size_t lz4f_mi355x_dev_compressFrameIndexed(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize,
