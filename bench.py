@@ -5,8 +5,10 @@
 
 One "step" = one pass of the hot path over one batch of synthetic input that is already resident in
 HBM: compress the stream into one LZ4 frame (find_matches -> layout -> emit kernels), then decompress
-that frame (decode kernel driven by the block table the compressor produced), all through the C ABI
-(lz4f_mi355x_dev_compressFrame / lz4f_mi355x_dev_decompressBlocks) on torch's current stream.
+that frame (block table and sequence index from the compressor: parse per index entry -> resolve direct matches ->
+copier workgroups), all through the C ABI (lz4f_mi355x_dev_compressFrameIndexed / lz4f_mi355x_dev_decompressBlocksIndexed)
+on torch's current stream.  `--no-index` runs the path a foreign frame takes (generic fused decoder); the default run
+reports that decoder's time too (`decode_without_index_ms`, measured after the timed region).
 Workload at every N: BASELINE configs[2] per GPU -- 4 GiB of synth50 (~50 % compressible), 4 MiB
 independent blocks; frame blocks are independent, so ranks shard the stream with no data-path
 collective ("weak" scaling: every rank gets its own 4 GiB with seed 1234+rank).
@@ -44,7 +46,7 @@ def pmc_traffic(kernel: str, n_bytes: int, block_size: int):
             prof = json.load(f)
         if n_bytes != (4 << 30) or block_size != (4 << 20):
             return None
-        names = {"find_matches": "k_find_matches<1>", "emit": "k_emit<4>", "decode": "k_decode_blocks_fused<lz4f::FzCfg<8> >"}
+        names = {"find_matches": "k_find_matches<1>", "emit": "k_emit<4>", "decode": "k_copy_indexed<lz4f::FzCfg<8> >"}
         return int(prof["kernels"][names[kernel]]["hbm_bytes_corrected"])
     except Exception:
         return None
@@ -89,6 +91,7 @@ def main():
     ap.add_argument("--block-checksum", type=int, default=0)
     ap.add_argument("--linked", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-index", action="store_true", help="decode without the compressor's sequence index (what a foreign frame gets)")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
     args = ap.parse_args()
 
@@ -120,12 +123,13 @@ def main():
     frame = torch.empty(eng.frame_bound(n, prefs), dtype=torch.uint8, device=dev)
     back = torch.empty_like(src)
     table = eng.new_table(nb)
+    index = None if (args.no_index or args.linked or bs < (256 << 10)) else eng.new_index(n, prefs)
     eng.set_timing(True)
 
     def step():
-        eng.compress_async(src, frame, prefs, table)
+        eng.compress_async(src, frame, prefs, table, index)
         # frame size is known on the device only; the decoder needs just an upper bound for bounds checks
-        eng.decompress_blocks_async(frame, frame.numel(), back, table, nb, prefs.frameInfo)
+        eng.decompress_blocks_async(frame, frame.numel(), back, table, nb, prefs.frameInfo, index)
 
     def barrier():
         shard.barrier_all(torch.device(dev))
@@ -133,7 +137,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    eng.compress_async(src, frame, prefs, table)
+    eng.compress_async(src, frame, prefs, table, index)
     r = eng.result()
     csize = int(r.size)
 
@@ -151,14 +155,25 @@ def main():
     dt = shard.max_over_ranks(dt, dev)
     r2 = eng.result()
     ok = bool(r2.size == n and torch.equal(back, src))
+    generic_ms = None
+    if index is not None and rank == 0:                       # the same frame through the generic decoder (no index), outside the timed region
+        t = []
+        for _ in range(3):
+            back.zero_()
+            eng.decompress_blocks_async(frame, frame.numel(), back, table, nb, prefs.frameInfo)
+            r3 = eng.result()
+            t.append(eng.get_timing()["decode"] + eng.get_timing()["finish"])
+            ok = ok and bool(r3.size == n and torch.equal(back, src))
+        generic_ms = round(min(t), 4)
 
     if rank == 0:
         total_u = n * world * args.steps
         value = total_u / dt / GIB
         mean = {k: (sum(v) / len(v)) for k, v in kt.items() if v and sum(v) > 0}
         algo = float(n + csize)               # U + C per direction; match copies served on-chip are not counted
-        kernels = {k: {"ms": round(ms, 4), "algo_GBs": round(algo / (ms * 1e-3) / 1e9, 1)} for k, ms in mean.items() if k in ("find_matches", "emit", "decode")}
-        dom = max(kernels, key=lambda k: kernels[k]["ms"]) if kernels else None
+        kernels = {k: {"ms": round(ms, 4), "algo_GBs": round(algo / (ms * 1e-3) / 1e9, 1)} for k, ms in mean.items()
+                   if k in ("find_matches", "emit", "decode", "decode_parse", "decode_copy")}
+        dom = max((k for k in kernels if not k.startswith("decode_")), key=lambda k: kernels[k]["ms"]) if kernels else None
         t_comp = sum(mean.get(k, 0.0) for k in ("find_matches", "layout", "emit", "xxh32_write"))
         t_dec = sum(mean.get(k, 0.0) for k in ("walk", "xxh32_verify", "decode", "finish"))
         out = {
@@ -167,14 +182,16 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "synth50 (~50%% compressible), %.0f GiB per GPU per step, %d KiB %s blocks, device-resident (inputs/outputs in HBM), "
-                                   "block checksums %s, content checksum off" % (n / GIB, bs >> 10, "linked" if args.linked else "independent",
-                                                                                "on" if args.block_checksum else "off"),
+                                   "block checksums %s, content checksum off, decode %s" % (n / GIB, bs >> 10, "linked" if args.linked else "independent",
+                                                                                "on" if args.block_checksum else "off",
+                                                                                "with the compressor's sequence index" if index is not None else "without index"),
                        "bytes_per_gpu": n, "block_size": bs, "n_blocks_per_gpu": nb, "generator": "synth50 recipe, torch Philox seed 1234+rank",
                        "sharding": "one 4 GiB stream per rank, no collective" if world > 1 else "single GPU"},
             "ratio": round(n / csize, 4), "compressed_bytes": csize, "roundtrip_verified": ok,
             "compress_GiBs_per_gpu": round(n / (t_comp * 1e-3) / GIB, 2) if t_comp else None,
             "decompress_GiBs_per_gpu": round(n / (t_dec * 1e-3) / GIB, 2) if t_dec else None,
             "kernels": kernels,
+            "decode_without_index_ms": generic_ms,
         }
         if dom:
             a = kernels[dom]["algo_GBs"]

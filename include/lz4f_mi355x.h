@@ -239,14 +239,18 @@ LZ4F_MI355X_API size_t lz4f_mi355x_dev_decompressBlocks(lz4f_mi355x_engine* e, v
  * token sits in the block's payload, which output position that sequence starts at and how many sequences follow;
  * with that table the decoder parses every chunk on its own lane and replays the copies out of an on-chip window
  * instead of walking one dependent chain per 4 MiB block (replaces the same inner loop of LZ4F_decompress,
- * Conduit.hsc:591).  Independent blocks only; a missing, stale or foreign index is detected and the generic decoder runs. */
-LZ4F_MI355X_API size_t lz4f_mi355x_dev_index_size(size_t srcSize, const LZ4F_preferences_t* prefs);       /* bytes to allocate for d_index */
+ * Conduit.hsc:591).  The decoder still parses the payload itself -- the index only says where it may start -- and checks
+ * that the pieces join up: a missing, stale or foreign index makes it fall back to the generic decoder, it cannot change
+ * the bytes that come out.  Independent blocks only.  A stream with more sequences than the index has room for (about one
+ * per 64 input bytes at the recommended size) gets an index marked unusable. */
+LZ4F_MI355X_API size_t lz4f_mi355x_dev_index_size(size_t srcSize, const LZ4F_preferences_t* prefs);       /* recommended bytes for d_index */
 LZ4F_MI355X_API size_t lz4f_mi355x_dev_compressFrameIndexed(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize,
                                                             const LZ4F_preferences_t* prefs, lz4f_mi355x_result* d_result,
-                                                            lz4f_mi355x_block* d_table, void* d_index);
+                                                            lz4f_mi355x_block* d_table, void* d_index, size_t indexCapacity);
 LZ4F_MI355X_API size_t lz4f_mi355x_dev_decompressBlocksIndexed(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_frame,
                                                                size_t frameCapacity, const lz4f_mi355x_block* d_table, uint32_t n_blocks,
-                                                               const LZ4F_frameInfo_t* info, const void* d_index, lz4f_mi355x_result* d_result);
+                                                               const LZ4F_frameInfo_t* info, const void* d_index, size_t indexSize,
+                                                               lz4f_mi355x_result* d_result);
 
 /* Per-block XXH32 of n_blocks byte ranges: d_out[i] = XXH32(d_base + off[i], len[i], 0) (row a5). */
 LZ4F_MI355X_API size_t lz4f_mi355x_dev_xxh32(lz4f_mi355x_engine* e, const void* d_base, const uint64_t* d_off,

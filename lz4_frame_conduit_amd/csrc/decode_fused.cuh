@@ -308,7 +308,6 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
         // fed descriptors: a DIRECT match is one more copy out of the payload (position in the bits of the offset + 7 more)
         const bool vdirect = FED && lane < count && (d.w >> 31) != 0;
         const uint32_t vmsrc = voff | (((d.w >> 24) & 0x7Fu) << 16);
-        const uint64_t direct_m = FED ? __ballot(vdirect) : 0ull;
 
         // ---- (1) literal runs (and direct matches): no dependencies.  A gather with no scalar work per run -- a CU has ONE
         // scalar unit, and a copy loop that spends ~100 scalar instructions per run is bound by it.  The runs of the slot are

@@ -37,6 +37,13 @@ __device__ __forceinline__ uint64_t pt_load8(const uint8_t* __restrict__ in, uin
     return v;
 }
 
+// 16 payload bytes at `pos` (same rule)
+__device__ __forceinline__ void pt_load16(const uint8_t* __restrict__ in, uint32_t pos, uint64_t readable, uint64_t& lo, uint64_t& hi)
+{
+    if ((uint64_t)pos + 16 <= readable) { typedef uint64_t u64u __attribute__((aligned(1))); lo = *(const u64u*)(in + pos); hi = *(const u64u*)(in + pos + 8); return; }
+    lo = pt_load8(in, pos, readable); hi = pt_load8(in, pos + 8, readable);
+}
+
 // k_parse_indexed, one lane per index entry.  (The index structures and k_build_index live in encode.cuh: pass E2 writes the entries.)
 // Input-side rules only (the feeder wave checks the ones that need output positions).  `flags[0]` is set when anything
 // disagrees with the index: the caller then falls back to the generic decoder.  Every entry must end exactly where the next
@@ -48,9 +55,17 @@ __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict
 {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const IxBlock* blocks = ix_blocks(ix);
-    if (gid < n_blocks) {                                                       // a compressed block without entries cannot be decoded from the index
+    if (gid < n_blocks) {
+        // the block table must hand out the descriptors and the entries without gaps or overlaps (every descriptor is then
+        // written by exactly one lane), and a compressed block without entries cannot be decoded from the index
         const IxBlock bk = blocks[gid];
-        if (!(table[gid].word >> 31) && (bk.nentries == 0 || bk.nseq == 0 || (uint64_t)bk.entry_base + bk.nentries > n_entries)) atomicOr(flags, 1u);
+        const bool stored = (table[gid].word >> 31) != 0;
+        bool wrong = stored ? (bk.nentries != 0 || bk.nseq != 0) : (bk.nentries == 0 || bk.nseq == 0);
+        if (gid == 0) wrong |= bk.seq_base != 0 || bk.entry_base != 0;
+        const uint64_t seq_end = (uint64_t)bk.seq_base + bk.nseq, ent_end = (uint64_t)bk.entry_base + bk.nentries;
+        if (gid + 1 < n_blocks) wrong |= blocks[gid + 1].seq_base != seq_end || blocks[gid + 1].entry_base != ent_end;
+        else wrong |= seq_end != desc_cap || ent_end != n_entries;
+        if (wrong) atomicOr(flags, 1u);
     }
     if (gid >= n_entries) return;
     const IxEntry* entries = ix_entries(ix, n_blocks);
@@ -76,9 +91,12 @@ __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict
     // range): a match that lies inside one is DIRECT -- a plain copy out of the payload that needs no earlier output
     uint32_t r0o = 0, r0n = 0, r0p = 0, r1o = 0, r1n = 0, r1p = 0, r2o = 0, r2n = 0, r2p = 0, r3o = 0, r3n = 0, r3p = 0;
     auto remember = [&](uint32_t o, uint32_t n, uint32_t pp) { r3o = r2o; r3n = r2n; r3p = r2p; r2o = r1o; r2n = r1n; r2p = r1p; r1o = r0o; r1n = r0n; r1p = r0p; r0o = o; r0n = n; r0p = pp; };
+    // One dependent load per sequence: the 16 bytes at the match offset also hold the match-length bytes, the NEXT token and
+    // its literal-length bytes (a lane walks its sequences at memory latency, so the loads on that chain are what counts).
+    uint64_t w, w_hi;
+    pt_load16(in, pos, readable, w, w_hi);
     for (uint32_t i = 0; i < my_nseq && !bad; i++) {
         if (pos >= csize) { bad = true; break; }
-        const uint64_t w = pt_load8(in, pos, readable);
         const uint32_t token = (uint32_t)w & 0xFF;
         uint32_t lit = token >> 4, p = pos + 1;
         if (lit == 15) {
@@ -95,19 +113,26 @@ __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict
             pos = csize;
         } else {
             const uint32_t q = p + lit;
-            const uint64_t w2 = pt_load8(in, q, readable);
+            uint64_t w2, w2_hi;
+            pt_load16(in, q, readable, w2, w2_hi);
             off = (uint32_t)w2 & 0xFFFF;
             if (off == 0) { bad = true; break; }
             mlen = token & 15; uint32_t pn = q + 2;
+            bool reload = false;
             if (mlen == 15) {
                 const uint64_t x = w2 >> 16;
                 const uint32_t f = (uint32_t)__builtin_ctzll(~x), k = f >> 3;
                 if (k < 6) { mlen += 255u * k + (uint32_t)((x >> (f & 56u)) & 0xFF); pn += k + 1; }
-                else { for (;;) { if (pn >= csize || mlen > (1u << 24)) { bad = true; break; } const uint32_t v = in[pn++]; mlen += v; if (v != 255) break; } if (bad) break; }
+                else { reload = true; for (;;) { if (pn >= csize || mlen > (1u << 24)) { bad = true; break; } const uint32_t v = in[pn++]; mlen += v; if (v != 255) break; } if (bad) break; }
                 if (pn + 4 >= csize) { bad = true; break; }
             }
             mlen += 4;
             pos = pn;
+            if (reload) pt_load16(in, pos, readable, w, w_hi);
+            else {                                                             // the next token is 2..8 bytes into what is already here
+                const uint32_t sh = (pn - q) * 8u;
+                w = sh >= 64 ? w2_hi : ((w2 >> sh) | (w2_hi << (64u - sh)));
+            }
         }
         uint32_t f24 = off, mw = mlen;
         if (lit) remember(op, lit, p);
@@ -137,7 +162,6 @@ __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict
 // that sequence's literal run: found.  Inside its match (not overlapping itself): the same question one offset further back,
 // a few hops at most.  Anything else (a source that straddles two runs, run-length matches) stays a match for the chain.
 // The descriptors are only read here; the answer goes to dsrc[i] (IX_NOT_DIRECT = none) and the feeder wave merges it in.
-constexpr uint32_t IXR_WGS = 16;                                // workgroups per block (grid-stride over its sequences)
 constexpr uint32_t IXR_HOPS = 6;
 constexpr uint32_t IX_NOT_DIRECT = 0xFFFFFFFFu;
 __global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, const ResultRec* __restrict__ res, uint32_t n_max,
@@ -151,7 +175,7 @@ __global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, c
     const IxBlock blk = ix_blocks(ix)[b];
     if ((uint64_t)blk.seq_base + blk.nseq > desc_cap) return;
     const SeqDesc* bd = desc + blk.seq_base;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < blk.nseq; i += IXR_WGS * 256) {
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < blk.nseq; i += gridDim.x * 256) {        // gridDim.x workgroups per block
         const SeqDesc d = bd[i];
         const uint32_t ml = d.w & 0xFFFFFFu;
         uint32_t found = IX_NOT_DIRECT;
@@ -189,7 +213,7 @@ __global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, c
 template <class C>
 __global__ __launch_bounds__(64 * C::WAVES, 8) void k_copy_indexed(const uint8_t* __restrict__ frame, uint8_t* dst, BlockOut* __restrict__ table,
                                                                    const ResultRec* __restrict__ res, uint32_t n_max, void* __restrict__ ix,
-                                                                   const SeqDesc* __restrict__ desc, const uint32_t* __restrict__ dsrc, const uint32_t* __restrict__ flags,
+                                                                   const SeqDesc* __restrict__ desc, const uint32_t* __restrict__ dsrc, uint32_t* __restrict__ flags,
                                                                    unsigned long long* prof)
 {
     __shared__ FzShared<C> sh;
@@ -213,7 +237,9 @@ __global__ __launch_bounds__(64 * C::WAVES, 8) void k_copy_indexed(const uint8_t
         got = fz_decode_block<C, true>(sh, frame + e.src_off, csz, dst + e.dst_off, e.dst_size, 0, frame, prof, desc + blk.seq_base, blk.nseq,
                                        dsrc ? dsrc + blk.seq_base : nullptr);
     }
-    if (tid == 0) table[b].dst_size = (uint32_t)got;
+    // A block that did not come out (descriptors that do not tile the output, a bad offset, no room) is left as it was and
+    // the generic kernel launched behind decodes the frame again: its verdict is the one the caller gets.
+    if (tid == 0) { if (got < 0) atomicOr(flags, 2u); else table[b].dst_size = (uint32_t)got; }
 }
 
 }  // namespace lz4f

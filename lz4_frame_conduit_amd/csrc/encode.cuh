@@ -381,19 +381,18 @@ __global__ __launch_bounds__(1024) void k_layout(EncGeom g, ChunkInfo* __restric
 //                                 exclusive scans over the blocks; the header
 //   pass E2                       writes the entries while it walks the records (it has both positions at hand)
 constexpr uint32_t IX_MAGIC = 0x3258494Cu;                     // "LIX2"
-constexpr uint32_t IX_STRIDE = 64;                             // sequences per entry
+constexpr uint32_t IX_STRIDE = 16;                             // sequences per entry (a lane of the decoder walks one entry at memory latency)
 struct IxHeader { uint32_t magic, n_blocks, chunks_per_block, total_seqs, total_entries, stride, pad0, pad1; };
 struct IxBlock  { uint32_t seq_base, nseq, entry_base, nentries; };    // nseq == 0: stored block / nothing to index
 struct IxChunk  { uint32_t ent_off, seq_off; };                // first entry / first sequence of the chunk within its block; ent_off bit 31: the block's final sequence follows this chunk's records
 struct IxEntry  { uint32_t in_off, out_pos, seq_off, nseq_blk; };      // payload offset, output position, first sequence (all within the block); sequences | block << 8
 __host__ __device__ inline uint32_t ix_max_entries_per_chunk(uint32_t chunk_size) { return (chunk_size / 4 + 1 + IX_STRIDE - 1) / IX_STRIDE + 1; }
+// What lz4f_mi355x_dev_index_size recommends: room for one sequence per 64 bytes of input on average.  Denser streams make
+// the compressor mark the index unusable (they are decoded by the generic kernels, which is the better choice for them anyway).
+__host__ __device__ inline size_t ix_typical_entries(uint64_t src_size, uint32_t n_chunks) { return (size_t)(src_size / (64u * IX_STRIDE)) + n_chunks + 64; }
 __host__ __device__ inline size_t ix_entries_at(uint32_t n_blocks, uint32_t chunks_per_block)
 {
     return sizeof(IxHeader) + (size_t)n_blocks * sizeof(IxBlock) + (size_t)n_blocks * chunks_per_block * sizeof(IxChunk);
-}
-__host__ __device__ inline size_t ix_bytes(uint32_t n_blocks, uint32_t chunks_per_block, uint32_t chunk_size)
-{
-    return ix_entries_at(n_blocks, chunks_per_block) + (size_t)n_blocks * chunks_per_block * ix_max_entries_per_chunk(chunk_size) * sizeof(IxEntry);
 }
 __device__ __forceinline__ IxBlock* ix_blocks(void* ix) { return (IxBlock*)((uint8_t*)ix + sizeof(IxHeader)); }
 __device__ __forceinline__ const IxBlock* ix_blocks(const void* ix) { return (const IxBlock*)((const uint8_t*)ix + sizeof(IxHeader)); }
@@ -406,7 +405,7 @@ __device__ __forceinline__ const IxEntry* ix_entries(const void* ix, uint32_t n_
 }
 
 __global__ __launch_bounds__(1024) void k_build_index(EncGeom g, const ChunkInfo* __restrict__ info, const BlockOut* __restrict__ table,
-                                                      const ResultRec* __restrict__ res, void* __restrict__ ix)
+                                                      const ResultRec* __restrict__ res, void* __restrict__ ix, uint64_t ix_capacity)
 {
     __shared__ uint32_t s_a[1024], s_b[1024];
     __shared__ uint32_t s_carry_a, s_carry_b;
@@ -414,6 +413,8 @@ __global__ __launch_bounds__(1024) void k_build_index(EncGeom g, const ChunkInfo
     IxHeader* hd = (IxHeader*)ix;
     IxBlock* blocks = ix_blocks(ix);
     IxChunk* chunks = ix_chunks(ix, g.n_blocks);
+    const size_t fixed = ix_entries_at(g.n_blocks, g.chunks_per_block);
+    if (ix_capacity < fixed) { if (t == 0 && ix_capacity >= sizeof(IxHeader)) hd->magic = 0; return; }
     const bool usable = res->status == ST_OK && !g.linked;
     // 1) per block: its chunks in order
     for (uint32_t b = t; b < g.n_blocks; b += 1024) {
@@ -451,7 +452,10 @@ __global__ __launch_bounds__(1024) void k_build_index(EncGeom g, const ChunkInfo
         if (t == 1023) { s_carry_a += s_a[1023]; s_carry_b += s_b[1023]; }
         __syncthreads();
     }
-    if (t == 0) *hd = IxHeader{usable ? IX_MAGIC : 0u, g.n_blocks, g.chunks_per_block, s_carry_a, s_carry_b, IX_STRIDE, 0u, 0u};
+    if (t == 0) {
+        const bool fits = (uint64_t)s_carry_b * sizeof(IxEntry) <= ix_capacity - fixed;     // else: too many sequences for this index, the decoder does without
+        *hd = IxHeader{usable && fits ? IX_MAGIC : 0u, g.n_blocks, g.chunks_per_block, s_carry_a, s_carry_b, IX_STRIDE, 0u, 0u};
+    }
 }
 
 // ------------------------------- pass E2 -------------------------------------------------------

@@ -157,7 +157,7 @@ extern "C" __attribute__((visibility("default"))) int lz4f_mi355x_debug_prof(uns
 }
 
 size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst, uint64_t dst_cap,
-                                           lz4f_mi355x_result* d_res, lz4f_mi355x_block* d_table, void* d_index)
+                                           lz4f_mi355x_result* d_res, lz4f_mi355x_block* d_table, void* d_index, size_t index_cap)
 {
     HIP_TRY(hipSetDevice(device));
     hipStream_t st = (hipStream_t)stream;
@@ -196,7 +196,7 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, g, (ChunkInfo*)info.p, (BlockOut*)d_table, (uint32_t*)blk_bytes.p,
                        d_dst, dst_cap, (ResultRec*)d_res);
     if (d_index)                                  // sequence index for the indexed decoder (entry points per 128 KiB chunk)
-        hipLaunchKernelGGL(k_build_index, dim3(1), dim3(1024), 0, st, g, (const ChunkInfo*)info.p, (const BlockOut*)d_table, (const ResultRec*)d_res, d_index);
+        hipLaunchKernelGGL(k_build_index, dim3(1), dim3(1024), 0, st, g, (const ChunkInfo*)info.p, (const BlockOut*)d_table, (const ResultRec*)d_res, d_index, (uint64_t)index_cap);
     tick(1, true);
     if (g.n_chunks) {
         tick(2, false);
@@ -256,7 +256,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         char mode = (j.linked || j.block_size >= (256u << 10)) ? 'f' : '1';
         if (const char* dv = getenv("LZ4F_MI355X_DECODE")) mode = dv[0];
         bool indexed = false;
-        if (mode == 'f' && j.d_index && !j.linked && !getenv("LZ4F_MI355X_NO_INDEX")) {
+        if (mode == 'f' && j.d_index && j.index_size >= sizeof(IxHeader) && !j.linked && !getenv("LZ4F_MI355X_NO_INDEX")) {
             // descriptors from the compressor's sequence index: a lane per entry parses, a workgroup per block copies out of an
             // LDS window.  The index header (16 bytes) is read back to size the descriptor workspace: the one host sync here.
             IxHeader hd; memset(&hd, 0, sizeof(hd));
@@ -264,7 +264,8 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             HIP_TRY(hipStreamSynchronize(st));
             const uint32_t chunk = pick_chunk_size(j.block_size), cpb = j.block_size / chunk;
             if (hd.magic == IX_MAGIC && hd.n_blocks == n_max && hd.chunks_per_block == cpb && hd.stride == IX_STRIDE &&
-                hd.total_entries <= (uint64_t)n_max * cpb * ix_max_entries_per_chunk(chunk) && hd.total_seqs <= (uint64_t)hd.total_entries * (IX_STRIDE + 1)) {
+                hd.total_entries <= (uint64_t)n_max * cpb * ix_max_entries_per_chunk(chunk) && hd.total_seqs <= (uint64_t)hd.total_entries * (IX_STRIDE + 1) &&
+                ix_entries_at(n_max, cpb) + (uint64_t)hd.total_entries * sizeof(IxEntry) <= j.index_size) {
                 const size_t dsrc_at = ((size_t)hd.total_seqs + 64) * sizeof(SeqDesc);
                 if (desc.ensure(dsrc_at + ((size_t)hd.total_seqs + 64) * 4) || seqcnt.ensure(256)) return make_err(LZ4F_ERROR_allocation_failed);
                 HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 32, st));
@@ -277,7 +278,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 uint32_t* dsrc = (uint32_t*)((uint8_t*)desc.p + dsrc_at);
                 if (getenv("LZ4F_MI355X_NO_RESOLVE")) dsrc = nullptr;
                 else
-                    hipLaunchKernelGGL(k_resolve_direct, dim3(IXR_WGS, n_max), dim3(256), 0, st, j.d_index, (const ResultRec*)d_res, n_max, (const SeqDesc*)desc.p,
+                    hipLaunchKernelGGL(k_resolve_direct, dim3(j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u, n_max), dim3(256), 0, st, j.d_index, (const ResultRec*)d_res, n_max, (const SeqDesc*)desc.p,
                                        dsrc, (uint64_t)hd.total_seqs, (uint32_t*)seqcnt.p, iprof ? 1u : 0u);
                 if (iprof) {                                                   // developer aid: how many matches are direct
                     uint32_t c[8];
@@ -288,10 +289,10 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 tick(9, false);
                 if (j.block_size <= (1u << 20))
                     hipLaunchKernelGGL(k_copy_indexed<FzCfg<4>>, dim3(n_max), dim3(64 * 4), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_max,
-                                       j.d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (const uint32_t*)seqcnt.p, iprof);
+                                       j.d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof);
                 else
                     hipLaunchKernelGGL(k_copy_indexed<FzCfg<8>>, dim3(n_max), dim3(64 * 8), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_max,
-                                       j.d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (const uint32_t*)seqcnt.p, iprof);
+                                       j.d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof);
                 tick(9, true);
                 indexed = true;
             }
@@ -594,11 +595,13 @@ size_t lz4f_mi355x_dev_index_size(size_t srcSize, const LZ4F_preferences_t* pref
     size_t bs = block_size_of(prefs ? prefs->frameInfo.blockSizeID : 0);
     if (!bs) bs = 65536;
     const uint32_t ch = pick_chunk_size((uint32_t)bs);
-    return ix_bytes((uint32_t)((srcSize + bs - 1) / bs), (uint32_t)(bs / ch), ch) + 64;
+    const uint32_t nb = (uint32_t)((srcSize + bs - 1) / bs), cpb = (uint32_t)(bs / ch);
+    return ix_entries_at(nb, cpb) + ix_typical_entries(srcSize, nb * cpb) * sizeof(IxEntry);
 }
 
 size_t lz4f_mi355x_dev_compressFrameIndexed(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize,
-                                            const LZ4F_preferences_t* prefs, lz4f_mi355x_result* d_result, lz4f_mi355x_block* d_table, void* d_index)
+                                            const LZ4F_preferences_t* prefs, lz4f_mi355x_result* d_result, lz4f_mi355x_block* d_table, void* d_index,
+                                            size_t indexCapacity)
 {
     if (!e || !d_table || !d_result) return make_err(LZ4F_ERROR_GENERIC);
     LZ4F_preferences_t p; memset(&p, 0, sizeof(p));
@@ -613,12 +616,12 @@ size_t lz4f_mi355x_dev_compressFrameIndexed(lz4f_mi355x_engine* e, void* d_dst, 
     j.d_src = (const uint8_t*)d_src; j.src_size = srcSize; j.first_off = 0; j.block_size = (uint32_t)bs;
     j.linked = p.frameInfo.blockMode == LZ4F_blockLinked; j.block_checksum = p.frameInfo.blockChecksumFlag != 0; j.endmark = true;
     j.header_size = (uint32_t)write_frame_header(j.header, p);
-    return e->launch_compress(j, (uint8_t*)d_dst, dstCapacity, d_result, d_table, d_index);
+    return e->launch_compress(j, (uint8_t*)d_dst, dstCapacity, d_result, d_table, d_index, d_index ? indexCapacity : 0);
 }
 
 size_t lz4f_mi355x_dev_decompressBlocksIndexed(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_frame, size_t frameCapacity,
                                                const lz4f_mi355x_block* d_table, uint32_t n_blocks, const LZ4F_frameInfo_t* info,
-                                               const void* d_index, lz4f_mi355x_result* d_result)
+                                               const void* d_index, size_t indexSize, lz4f_mi355x_result* d_result)
 {
     if (!e || !d_table || !info) return make_err(LZ4F_ERROR_GENERIC);
     const size_t bs = block_size_of(info->blockSizeID);
@@ -626,7 +629,7 @@ size_t lz4f_mi355x_dev_decompressBlocksIndexed(lz4f_mi355x_engine* e, void* d_ds
     lz4f_mi355x_engine::DecompressJob j; memset(&j, 0, sizeof(j));
     j.d_frame = (const uint8_t*)d_frame; j.frame_cap = frameCapacity; j.d_dst = (uint8_t*)d_dst; j.dst_cap = dstCapacity; j.hist0 = 0;
     j.block_size = (uint32_t)bs; j.linked = info->blockMode == LZ4F_blockLinked; j.block_checksum = info->blockChecksumFlag != 0;
-    j.d_table = d_table; j.n_blocks = n_blocks; j.max_blocks = n_blocks; j.d_index = (void*)d_index;
+    j.d_table = d_table; j.n_blocks = n_blocks; j.max_blocks = n_blocks; j.d_index = (void*)d_index; j.index_size = d_index ? indexSize : 0;
     return e->launch_decompress(j, d_result);
 }
 

@@ -69,10 +69,10 @@ struct lz4f_mi355x_engine {
     };
     // returns 0 or an LZ4F error; d_res/d_table may be null (internal buffers are used)
     size_t launch_compress(const CompressJob& j, uint8_t* d_dst, uint64_t dst_cap, lz4f_mi355x_result* d_res, lz4f_mi355x_block* d_table,
-                           void* d_index = nullptr);
+                           void* d_index = nullptr, size_t index_cap = 0);
     struct DecompressJob {
         const uint8_t* d_frame; uint64_t frame_cap; uint8_t* d_dst; uint64_t dst_cap; uint64_t hist0;
-        void* d_index;               // sequence index written by launch_compress (optional; independent blocks only)
+        void* d_index; size_t index_size;   // sequence index written by launch_compress (optional; independent blocks only)
         uint32_t block_size; bool linked; bool block_checksum;
         const lz4f_mi355x_block* d_table; uint32_t n_blocks;     // when d_table != null the walk is skipped
         bool table_in_place;                                     // the engine's own table already holds n_blocks entries

@@ -70,9 +70,9 @@ class Engine:
         With `index` (new_index) the compressor also leaves its sequence index there for decompress_blocks_async."""
         assert src.dtype == torch.uint8 and dst.dtype == torch.uint8 and src.is_cuda and dst.is_cuda
         if index is not None:
-            assert table is not None and index.numel() >= self.index_size(src.numel(), prefs)
+            assert table is not None and index.dtype == torch.uint8 and index.is_cuda
             _chk(self.L, self.L.lz4f_mi355x_dev_compressFrameIndexed(self.h, dst.data_ptr(), dst.numel(), src.data_ptr(), src.numel(), ctypes.byref(prefs),
-                                                                    self._res.data_ptr(), table.data_ptr(), index.data_ptr()))
+                                                                    self._res.data_ptr(), table.data_ptr(), index.data_ptr(), index.numel()))
             return
         _chk(self.L, self.L.lz4f_mi355x_dev_compressFrame(self.h, dst.data_ptr(), dst.numel(), src.data_ptr(), src.numel(), ctypes.byref(prefs),
                                                          self._res.data_ptr(), table.data_ptr() if table is not None else None))
@@ -81,7 +81,7 @@ class Engine:
                                 index: "torch.Tensor | None" = None):
         if index is not None:
             _chk(self.L, self.L.lz4f_mi355x_dev_decompressBlocksIndexed(self.h, dst.data_ptr(), dst.numel(), frame.data_ptr(), frame_len, table.data_ptr(),
-                                                                       n_blocks, ctypes.byref(info), index.data_ptr(), self._res.data_ptr()))
+                                                                       n_blocks, ctypes.byref(info), index.data_ptr(), index.numel(), self._res.data_ptr()))
             return
         _chk(self.L, self.L.lz4f_mi355x_dev_decompressBlocks(self.h, dst.data_ptr(), dst.numel(), frame.data_ptr(), frame_len, table.data_ptr(),
                                                             n_blocks, ctypes.byref(info), self._res.data_ptr()))

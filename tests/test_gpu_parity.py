@@ -518,3 +518,115 @@ def test_linked_frames_windowed_and_fallback(L, named_inputs):
             assert gv == "ok" and got == want, (pos, gv)
         else:
             assert gv != "ok", (pos, verdict)
+
+
+def _indexed_inputs():
+    rng = np.random.default_rng(5)
+    yield "synth50", datagen.synth50(12 << 20, 91)
+    yield "synth50-ragged", datagen.synth50(9 << 20, 92)[: (9 << 20) - 12345]
+    for i in range(4):
+        yield "structured-%d" % i, np.frombuffer(datagen.structured((5 << 20) + 777 * i, 3100 + i), dtype=np.uint8).copy()
+    yield "text", datagen.synth_text(6 << 20, 17)
+    yield "zeros", np.zeros(5 << 20, dtype=np.uint8)
+    yield "period-3", np.tile(np.frombuffer(b"abc", dtype=np.uint8), (4 << 20) // 3 + 1)[: 4 << 20].copy()
+    mixed = np.concatenate([rng.integers(0, 256, 3 << 20, dtype=np.uint8), datagen.synth50(4 << 20, 93), rng.integers(0, 256, 1 << 20, dtype=np.uint8)])
+    yield "stored-blocks-mixed", mixed
+    yield "tiny", np.frombuffer(b"hello hello hello hello hello hello hello hello", dtype=np.uint8).copy()
+
+
+def test_indexed_decode_same_bytes_as_generic(L):
+    """The compressor's sequence index only tells the decoder where it may start parsing: with it (indexed kernels) and
+    without it (generic kernels) the same frame gives the same bytes, for every block size the indexed path takes."""
+    import torch
+    from lz4_frame_conduit_amd.device import Engine
+    eng = Engine(0)
+    used = 0
+    for name, data in _indexed_inputs():
+        for bsid in (5, 6, 7):
+            kw = dict(bsid=bsid, indep=1, bck=1 if bsid == 6 else 0)
+            src = torch.from_numpy(data).cuda()
+            p = prefs_of(kw)
+            bs = 1 << (8 + 2 * bsid)
+            nb = (src.numel() + bs - 1) // bs
+            frame = torch.empty(eng.frame_bound(src.numel(), p), dtype=torch.uint8, device="cuda")
+            table, index = eng.new_table(nb), eng.new_index(src.numel(), p)
+            eng.compress_async(src, frame, p, table, index)
+            r = eng.result()
+            plain = torch.empty_like(frame)
+            eng.compress_async(src, plain, p, eng.new_table(nb))
+            rp = eng.result()
+            assert rp.size == r.size and torch.equal(plain[:r.size], frame[:r.size]), (name, kw)      # the frame does not depend on the index
+            hd = index[:32].cpu().numpy().view(np.uint32)
+            used += int(hd[0] == 0x3258494C)
+            back = torch.zeros_like(src)
+            eng.decompress_blocks_async(frame, r.size, back, table, nb, p.frameInfo, index)
+            r2 = eng.result()
+            assert r2.size == src.numel() and torch.equal(back, src), (name, kw)
+            back.zero_()
+            eng.decompress_blocks_async(frame, r.size, back, table, nb, p.frameInfo)
+            r3 = eng.result()
+            assert r3.size == src.numel() and torch.equal(back, src), (name, kw)
+    assert used >= 20                                                         # (dense streams may legitimately get an unusable index)
+    eng.close()
+
+
+def test_indexed_decode_survives_wrong_indexes(L):
+    """A stale, foreign, truncated or corrupted index must never change the output: the decoder notices and falls back."""
+    import torch
+    from lz4_frame_conduit_amd.device import Engine
+    eng = Engine(0)
+    rng = np.random.default_rng(11)
+    a = np.frombuffer(datagen.structured(9 << 20, 4200), dtype=np.uint8).copy()
+    b = datagen.synth50(9 << 20, 4201)
+    p = prefs_of(dict(bsid=6, indep=1))
+    nb = 9
+
+    def pack(data):
+        src = torch.from_numpy(data).cuda()
+        frame = torch.empty(eng.frame_bound(src.numel(), p), dtype=torch.uint8, device="cuda")
+        table, index = eng.new_table(nb), eng.new_index(src.numel(), p)
+        eng.compress_async(src, frame, p, table, index)
+        return src, frame, table, index, eng.result().size
+
+    sa, fa, ta, ia, na = pack(a)
+    sb, fb, tb, ib, nb_sz = pack(b)
+    assert int(ia[:4].cpu().numpy().view(np.uint32)[0]) == 0x3258494C and int(ib[:4].cpu().numpy().view(np.uint32)[0]) == 0x3258494C
+
+    def check(src, frame, table, size, index):
+        back = torch.zeros_like(src)
+        eng.decompress_blocks_async(frame, size, back, table, nb, p.frameInfo, index)
+        r = eng.result()
+        assert r.size == src.numel() and torch.equal(back, src)
+
+    check(sa, fa, ta, na, ib)                                                 # another stream's index, same geometry
+    check(sb, fb, tb, nb_sz, ia)
+    check(sa, fa, ta, na, torch.zeros_like(ia))                               # never written
+    check(sa, fa, ta, na, ia[:64].clone())                                    # truncated behind the header
+    check(sa, fa, ta, na, torch.from_numpy(rng.integers(0, 256, ia.numel(), dtype=np.uint8)).cuda())
+    hd = ia[:32].cpu().numpy().view(np.uint32)
+    n_entries = int(hd[4])
+    fixed = 32 + nb * 16 + nb * int(hd[2]) * 8
+    for trial in range(24):                                                   # one damaged word somewhere in the tables
+        bad = ia.clone()
+        words = bad[: fixed + n_entries * 16].view(torch.int32)
+        at = int(rng.integers(8, words.numel()))
+        words[at] = int(words[at].item()) ^ (1 << int(rng.integers(0, 24)))
+        check(sa, fa, ta, na, bad)
+    small = torch.zeros(fixed + 16, dtype=torch.uint8, device="cuda")         # too small for the stream: the compressor says so in the header
+    src = torch.from_numpy(a).cuda()
+    frame = torch.empty_like(fa)
+    table = eng.new_table(nb)
+    eng.compress_async(src, frame, p, table, small)
+    r = eng.result()
+    assert int(small[:4].cpu().numpy().view(np.uint32)[0]) == 0
+    check(src, frame, table, r.size, small)
+    # linked frames ignore the index
+    pl = prefs_of(dict(bsid=6, indep=0))
+    frame_l = torch.empty(eng.frame_bound(src.numel(), pl), dtype=torch.uint8, device="cuda")
+    idx = eng.new_index(src.numel(), pl)
+    eng.compress_async(src, frame_l, pl, table, idx)
+    r = eng.result()
+    back = torch.zeros_like(src)
+    eng.decompress_blocks_async(frame_l, r.size, back, table, nb, pl.frameInfo, idx)
+    assert eng.result().size == src.numel() and torch.equal(back, src)
+    eng.close()

@@ -23,8 +23,8 @@ def run(src, label):
         back.zero_()
         eng.decompress_blocks_async(frame, frame.numel(), back, table, nb, p.frameInfo, index); r2 = eng.result(); td = eng.get_timing()
     ok = bool(torch.equal(back, src)) and r2.size == n
-    hd = index[:16].cpu().numpy().view(np.uint32)
-    print(label, "ok", ok, "ratio %.4f" % (n / r.size), "seqs", int(hd[3]), {k: round(v, 3) for k, v in {**tc, **td}.items() if v > 0}, flush=True)
+    hd = index[:32].cpu().numpy().view(np.uint32)
+    print(label, "ok", ok, "ratio %.4f" % (n / r.size), "index", "usable" if hd[0] == 0x3258494C else "UNUSABLE", "seqs", int(hd[3]), "entries", int(hd[4]), {k: round(v, 3) for k, v in {**tc, **td}.items() if v > 0}, flush=True)
     if not ok:
         d = (back != src).nonzero()
         print("  first diff at", int(d[0]) if len(d) else None, "of", n, "n diffs", len(d), "size", r2.size)
