@@ -30,8 +30,11 @@ template <int W> struct FzCfg;
 template <> struct FzCfg<8> { static constexpr int WAVES = 8; static constexpr uint32_t STAGE = 8192, RING = 8, LDS_BUDGET = 40960; };
 template <> struct FzCfg<4> { static constexpr int WAVES = 4; static constexpr uint32_t STAGE = 2048, RING = 4, LDS_BUDGET = 20480; };
 constexpr uint32_t FZ_OVER = 576;                // >= the parser's 520-byte register window + 8
-#ifndef FZ_FED_DEPTH
-#define FZ_FED_DEPTH 4
+#ifndef FZ_FED_ROUNDS
+#define FZ_FED_ROUNDS 1                          // gather rounds per register set in the fed copiers (two sets in flight)
+#endif
+#ifndef FZ_FED_OCC
+#define FZ_FED_OCC 8
 #endif
 constexpr int      FZ_MATCH_SET = 3;            // match copies per register set (two sets in flight)
 
@@ -367,19 +370,29 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
                     if (FED) __builtin_nontemporal_store(u32x4{pc.a, pc.b, pc.c, pc.d}, (u32x4_ua*)(out + dof));
                     else *(v4u_ua*)(out + dof) = v4u_ua{pc.a, pc.b, pc.c, pc.d};
                 };
-                Piece a0, b0;                                                   // ping-pong, one round each: a load is in flight while the previous round is stored
-                uint32_t da0, db0;
-                bool xa0, xb0;
+                // ping-pong of G rounds each: loads are in flight while the previous set is stored
+                constexpr int G = FED ? FZ_FED_ROUNDS : 1;
+                Piece pa[G], pb[G];
+                uint32_t da[G], db[G];
+                bool xa[G], xb[G];
                 uint32_t base = 0;
-                ld(a0, base + lane, da0, xa0); base += 64;
+#pragma unroll
+                for (int i = 0; i < G; i++) ld(pa[i], base + 64 * i + lane, da[i], xa[i]);
+                base += 64 * G;
                 for (;;) {
                     const bool more_b = base < total;
-                    ld(b0, base + lane, db0, xb0); base += 64;
-                    st(a0, da0, xa0);
+#pragma unroll
+                    for (int i = 0; i < G; i++) ld(pb[i], base + 64 * i + lane, db[i], xb[i]);
+                    base += 64 * G;
+#pragma unroll
+                    for (int i = 0; i < G; i++) st(pa[i], da[i], xa[i]);
                     if (!more_b) break;
                     const bool more_a = base < total;
-                    ld(a0, base + lane, da0, xa0); base += 64;
-                    st(b0, db0, xb0);
+#pragma unroll
+                    for (int i = 0; i < G; i++) ld(pa[i], base + 64 * i + lane, da[i], xa[i]);
+                    base += 64 * G;
+#pragma unroll
+                    for (int i = 0; i < G; i++) st(pb[i], db[i], xb[i]);
                     if (!more_a) break;
                 }
             }

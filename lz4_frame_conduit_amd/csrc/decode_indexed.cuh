@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, c
 // One workgroup per block: the fused decoder's copier waves (decode_fused.cuh), fed from the descriptor array instead of
 // by a parser wave.
 template <class C>
-__global__ __launch_bounds__(64 * C::WAVES, 8) void k_copy_indexed(const uint8_t* __restrict__ frame, uint8_t* dst, BlockOut* __restrict__ table,
+__global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(const uint8_t* __restrict__ frame, uint8_t* dst, BlockOut* __restrict__ table,
                                                                    const ResultRec* __restrict__ res, uint32_t n_max, void* __restrict__ ix,
                                                                    const SeqDesc* __restrict__ desc, const uint32_t* __restrict__ dsrc, uint32_t* __restrict__ flags,
                                                                    unsigned long long* prof)

@@ -21,6 +21,7 @@
 // The output is a valid LZ4 block (end-of-block rules of Appendix A.2 are enforced); it is not
 // byte-identical to liblz4's -- parity is round-trip identity + ratio tolerance (tests/).
 #pragma once
+#include <type_traits>
 #include "common.cuh"
 
 namespace lz4f {
@@ -78,18 +79,23 @@ __device__ __forceinline__ uint64_t ld64_guard(const uint8_t* p, const uint8_t* 
 }
 
 // ------------------------------- pass E1 -------------------------------------------------------
+#ifndef E1_TAG_BITS
+#define E1_TAG_BITS 8
+#endif
+constexpr uint32_t TAG_BITS = E1_TAG_BITS, TAG_MASK = (1u << TAG_BITS) - 1;
+typedef std::conditional<(E1_TAG_BITS > 8), uint16_t, uint8_t>::type tag_t;
 // grid: one wave per chunk (blockDim = 64 * WAVES_PER_WG)
 template <int WAVES_PER_WG>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_t* __restrict__ src, EncGeom g,
                                                                     ChunkInfo* __restrict__ info, uint64_t* __restrict__ recs)
 {
     __shared__ uint16_t s_table[WAVES_PER_WG][HASH_SIZE];
-    __shared__ uint8_t s_tag[WAVES_PER_WG][HASH_SIZE];      // 8 more hash bits per entry: filters false candidates without touching memory
+    __shared__ tag_t s_tag[WAVES_PER_WG][HASH_SIZE];        // TAG_BITS more hash bits per entry: filters false candidates without touching memory
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
     const uint32_t chunk = uni(blockIdx.x * WAVES_PER_WG + wave);
     if (chunk >= g.n_chunks) return;
     uint16_t* table = s_table[wave];
-    uint8_t* tags = s_tag[wave];
+    tag_t* tags = s_tag[wave];
 
     const uint32_t blk = chunk / g.chunks_per_block, cib = chunk % g.chunks_per_block;
     const uint64_t bstart = g.first_off + (uint64_t)blk * g.block_size;
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
     // 64 KiB of positions, and later inserts win: seed the whole window sparsely (every SEED_STRIDE-th position,
     // roughly the density the skip-accelerated search itself leaves behind), then the last SEED_DENSE bytes densely.
     for (uint32_t i = lane; i < HASH_SIZE / 2; i += WAVE) ((uint32_t*)table)[i] = 0;
-    for (uint32_t i = lane; i < HASH_SIZE / 4; i += WAVE) ((uint32_t*)tags)[i] = 0;
+    for (uint32_t i = lane; i < HASH_SIZE * sizeof(tag_t) / 4; i += WAVE) ((uint32_t*)tags)[i] = 0;
     if (back >= 4) {
         const uint32_t dense_from = back > g.seed_dense ? back - g.seed_dense : 0;
         const uint32_t ss = g.seed_stride;
@@ -122,11 +128,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
 #pragma unroll
             for (int u = 0; u < 4; u++) { pp[u] = q + (u * WAVE + lane) * ss; vv[u] = ld32(base + (pp[u] < dense_from ? pp[u] : 0u)); }
 #pragma unroll
-            for (int u = 0; u < 4; u++) if (pp[u] < dense_from) { const uint32_t hv = vv[u] * 2654435761u; table[hv >> (32 - HASH_LOG)] = (uint16_t)pp[u]; tags[hv >> (32 - HASH_LOG)] = (uint8_t)(hv >> (24 - HASH_LOG)); }
+            for (int u = 0; u < 4; u++) if (pp[u] < dense_from) { const uint32_t hv = vv[u] * 2654435761u; table[hv >> (32 - HASH_LOG)] = (uint16_t)pp[u]; tags[hv >> (32 - HASH_LOG)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
         }
         for (uint32_t q = dense_from; q + 4 <= back; q += WAVE) {
             const uint32_t p = q + lane;
-            if (p + 4 <= back) { const uint32_t hv = ld32(base + p) * 2654435761u; table[hv >> (32 - HASH_LOG)] = (uint16_t)p; tags[hv >> (32 - HASH_LOG)] = (uint8_t)(hv >> (24 - HASH_LOG)); }
+            if (p + 4 <= back) { const uint32_t hv = ld32(base + p) * 2654435761u; table[hv >> (32 - HASH_LOG)] = (uint16_t)p; tags[hv >> (32 - HASH_LOG)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
         }
     }
 
@@ -173,9 +179,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
             // ---- probe A ----
             const uint32_t pA = ip + lane * step;
             const bool actA = pA <= last_start;
-            const uint32_t hvA = seqA * hmul, hA = hvA >> (32 - HASH_LOG), tgA = (hvA >> (24 - HASH_LOG)) & 0xFFu;
-            uint32_t eA = 0, tA = 0x100;
-            if (actA) { eA = table[hA]; tA = tags[hA]; table[hA] = (uint16_t)pA; tags[hA] = (uint8_t)tgA; }
+            const uint32_t hvA = seqA * hmul, hA = hvA >> (32 - HASH_LOG), tgA = (hvA >> (32 - TAG_BITS - HASH_LOG)) & TAG_MASK;
+            uint32_t eA = 0, tA = TAG_MASK + 1;
+            if (actA) { eA = table[hA]; tA = tags[hA]; table[hA] = (uint16_t)pA; tags[hA] = (tag_t)tgA; }
             const uint32_t dA = (pA - eA) & 0xFFFFu;
             const bool okA = actA && tA == tgA && dA != 0 && dA <= pA;            // same 20 hash bits: worth a look at the bytes
             const uint32_t candA = pA - dA;
@@ -184,9 +190,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
             const uint32_t seqB = s1;
             const uint32_t pB = ipB + lane * stepB;
             const bool actB = pB <= last_start;
-            const uint32_t hvB = seqB * hmul, hB = hvB >> (32 - HASH_LOG), tgB = (hvB >> (24 - HASH_LOG)) & 0xFFu;
-            uint32_t eB = 0, tB = 0x100;
-            if (actB) { eB = table[hB]; tB = tags[hB]; table[hB] = (uint16_t)pB; tags[hB] = (uint8_t)tgB; }
+            const uint32_t hvB = seqB * hmul, hB = hvB >> (32 - HASH_LOG), tgB = (hvB >> (32 - TAG_BITS - HASH_LOG)) & TAG_MASK;
+            uint32_t eB = 0, tB = TAG_MASK + 1;
+            if (actB) { eB = table[hB]; tB = tags[hB]; table[hB] = (uint16_t)pB; tags[hB] = (tag_t)tgB; }
             const uint32_t dB = (pB - eB) & 0xFFFFu;
             const bool okB = actB && tB == tgB && dB != 0 && dB <= pB;
             const uint32_t candB = pB - dB;
@@ -227,12 +233,12 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
             // lanes of a step can share a table slot (periodic data): a lane beyond the hit restoring "its" old value would
             // also wipe the insert of a lane up to the hit, so those are written again afterwards.
             if (!hitB) {
-                if (actB) { table[hB] = (uint16_t)eB; tags[hB] = (uint8_t)tB; }
-                if (actA && lane > L) { table[hA] = (uint16_t)eA; tags[hA] = (uint8_t)tA; }
-                if (actA && lane <= L) { table[hA] = (uint16_t)pA; tags[hA] = (uint8_t)tgA; }
+                if (actB) { table[hB] = (uint16_t)eB; tags[hB] = (tag_t)tB; }
+                if (actA && lane > L) { table[hA] = (uint16_t)eA; tags[hA] = (tag_t)tA; }
+                if (actA && lane <= L) { table[hA] = (uint16_t)pA; tags[hA] = (tag_t)tgA; }
             } else {
-                if (actB && lane > L) { table[hB] = (uint16_t)eB; tags[hB] = (uint8_t)tB; }
-                if (actB && lane <= L) { table[hB] = (uint16_t)pB; tags[hB] = (uint8_t)tgB; }
+                if (actB && lane > L) { table[hB] = (uint16_t)eB; tags[hB] = (tag_t)tB; }
+                if (actB && lane <= L) { table[hB] = (uint16_t)pB; tags[hB] = (tag_t)tgB; }
             }
             uint32_t mlen = 0;
             {
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
             const uint32_t q2 = ins2 ? ip - 2 : cs;
             const uint32_t v2 = ld32(base + q2);
             fill_queue();
-            if (ins2) { const uint32_t hv = v2 * hmul; table[hv >> (32 - HASH_LOG)] = (uint16_t)q2; tags[hv >> (32 - HASH_LOG)] = (uint8_t)(hv >> (24 - HASH_LOG)); }
+            if (ins2) { const uint32_t hv = v2 * hmul; table[hv >> (32 - HASH_LOG)] = (uint16_t)q2; tags[hv >> (32 - HASH_LOG)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
         }
     }
     if (lane == 0) { ci->nrec = nrec; ci->first_lit = first_lit; ci->tail_lit = ce - anchor; ci->body_size = body; }
