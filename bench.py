@@ -37,17 +37,21 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 
 HBM_COPY_GBS = 6290.0
 
 
-def pmc_traffic(kernel: str, n_bytes: int, block_size: int):
+def pmc_traffic(kernel: str, n_bytes: int, block_size: int, indexed: bool = True):
     """HBM bytes per launch of `kernel` from the committed PMC profile (rocprofv3 cannot run inside the timed process:
-    counters are collected in their own passes, see profiles/round1_pmc_traffic.json), or None when that profile was
+    counters are collected in their own passes, see profiles/round1b_pmc_traffic.json), or None when that profile was
     not taken on this workload."""
     try:
-        with open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")) as f:
-            prof = json.load(f)
         if n_bytes != (4 << 30) or block_size != (4 << 20):
             return None
-        names = {"find_matches": "k_find_matches<1>", "emit": "k_emit<4>", "decode": "k_copy_indexed<lz4f::FzCfg<8> >"}
-        return int(prof["kernels"][names[kernel]]["hbm_bytes_corrected"])
+        if kernel == "decode" and not indexed:
+            with open(os.path.join(ROOT, "profiles", "round1_pmc_traffic.json")) as f:
+                return int(json.load(f)["kernels"]["k_decode_blocks_fused<lz4f::FzCfg<8> >"]["hbm_bytes_corrected"])
+        with open(os.path.join(ROOT, "profiles", "round1b_pmc_traffic.json")) as f:
+            prof = json.load(f)
+        names = {"find_matches": ["k_find_matches<1>"], "emit": ["k_emit<4>"],
+                 "decode": ["k_parse_indexed", "k_resolve_direct", "k_copy_indexed<FzCfg<8> >"]}
+        return int(sum(prof["kernels"][k]["hbm_bytes_corrected"] for k in names[kernel]))
     except Exception:
         return None
 
@@ -196,13 +200,14 @@ def main():
         if dom:
             a = kernels[dom]["algo_GBs"]
             out["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": a, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(a / HBM_PEAK_GBS, 4),
-                               "traffic": pmc_traffic(dom, n, bs), "traffic_source": "profiles/round1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)",
+                               "traffic": pmc_traffic(dom, n, bs, index is not None), "traffic_source": "profiles/round1b_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950-corrected)",
                                "algorithmic_bytes_per_launch": int(algo), "ms_per_launch": kernels[dom]["ms"],
                                "frac_of_measured_copy_peak": round(a / HBM_COPY_GBS, 4)}
             if "decode" in kernels:
                 d = kernels["decode"]["algo_GBs"]
                 out["roofline_decode"] = {"bound": "hbm", "achieved": d, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d / HBM_PEAK_GBS, 4),
-                                          "traffic": pmc_traffic("decode", n, bs)}
+                                          "traffic": pmc_traffic("decode", n, bs, index is not None),
+                                          "kernels": "k_parse_indexed + k_resolve_direct + k_copy_indexed + k_finish_decode" if index is not None else "k_decode_blocks_fused + k_finish_decode"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(bs, args.cpu_sample_mib << 20)
