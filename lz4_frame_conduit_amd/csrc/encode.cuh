@@ -316,15 +316,23 @@ __global__ __launch_bounds__(1024) void k_layout(EncGeom g, ChunkInfo* __restric
         ChunkInfo* ci = info + (uint64_t)b * g.chunks_per_block;
         const uint32_t nch = (blen + g.chunk_size - 1) / g.chunk_size;
         uint32_t carry = 0, total = 0;
-        for (uint32_t c = 0; c < nch; c++) {
-            ChunkInfo x = ci[c];
-            ci[c].carry_in = carry;
-            ci[c].out_off = total;                 // relative for now
-            ci[c].flags = (c + 1 == nch) ? 2u : 0u;
-            if (x.nrec) {
-                total += x.body_size + carry + len_ext_bytes(x.first_lit + carry) - len_ext_bytes(x.first_lit);
-                carry = x.tail_lit;
-            } else carry += x.tail_lit;
+        // (eight summaries are fetched together: one thread walks a block's chunks, and a load per step would make this
+        // kernel a chain of 32 memory round trips)
+        for (uint32_t c0 = 0; c0 < nch; c0 += 8) {
+            uint4 x[8];                             // {nrec, first_lit, tail_lit, body_size}
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) x[k] = (c0 + k < nch) ? *(const uint4*)&ci[c0 + k] : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t c = c0 + k;
+                if (c >= nch) break;
+                *(uint2*)&ci[c].carry_in = uint2{carry, (c + 1 == nch) ? 2u : 0u};      // carry_in, flags
+                ci[c].out_off = total;              // relative for now
+                if (x[k].x) {
+                    total += x[k].w + carry + len_ext_bytes(x[k].y + carry) - len_ext_bytes(x[k].y);
+                    carry = x[k].z;
+                } else carry += x[k].z;
+            }
         }
         total += 1 + len_ext_bytes(carry) + carry;  // final literal-only sequence
         const bool raw = total >= blen;             // LZ4F stores raw when it does not fit blockSize-1
@@ -367,8 +375,14 @@ __global__ __launch_bounds__(1024) void k_layout(EncGeom g, ChunkInfo* __restric
             ChunkInfo* ci = info + (uint64_t)b * g.chunks_per_block;
             const uint32_t blen = table[b].dst_size;
             const uint32_t nch = (blen + g.chunk_size - 1) / g.chunk_size;
-            for (uint32_t c = 0; c < nch; c++)
-                ci[c].out_off = (w >> 31) ? pay + (uint64_t)c * g.chunk_size : pay + ci[c].out_off;
+            for (uint32_t c0 = 0; c0 < nch; c0 += 8) {
+                uint64_t rel[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) rel[k] = (c0 + k < nch) ? ci[c0 + k].out_off : 0;
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++)
+                    if (c0 + k < nch) ci[c0 + k].out_off = (w >> 31) ? pay + (uint64_t)(c0 + k) * g.chunk_size : pay + rel[k];
+            }
         }
         if (t < g.header_size) dst[t] = g.header[t];
         if (t < 4 && g.write_endmark) dst[s_carry + t] = 0;
@@ -429,10 +443,16 @@ __global__ __launch_bounds__(1024) void k_build_index(EncGeom g, const ChunkInfo
         IxChunk* ck = chunks + (uint64_t)b * g.chunks_per_block;
         const uint32_t nch = (e.dst_size + g.chunk_size - 1) / g.chunk_size;
         uint32_t nseq = 0, nent = 0, last = 0xFFFFFFFFu;
-        for (uint32_t c = 0; c < g.chunks_per_block; c++) {
-            ck[c] = IxChunk{nent, nseq};
-            if (usable && !(e.word >> 31) && c < nch && ci[c].nrec) {
-                nseq += ci[c].nrec; nent += (ci[c].nrec + IX_STRIDE - 1) / IX_STRIDE; last = c;
+        for (uint32_t c0 = 0; c0 < g.chunks_per_block; c0 += 8) {
+            uint32_t nr[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) nr[k] = (c0 + k < nch) ? ci[c0 + k].nrec : 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t c = c0 + k;
+                if (c >= g.chunks_per_block) break;
+                ck[c] = IxChunk{nent, nseq};
+                if (usable && !(e.word >> 31) && nr[k]) { nseq += nr[k]; nent += (nr[k] + IX_STRIDE - 1) / IX_STRIDE; last = c; }
             }
         }
         if (last != 0xFFFFFFFFu) { ck[last].ent_off |= 0x80000000u; nseq += 1; }     // the block's final literal-only sequence

@@ -15,7 +15,7 @@ bs = 1 << (8 + 2 * bsid)
 def run(src, label):
     n = src.numel()
     frame = torch.empty(eng.frame_bound(n, p), dtype=torch.uint8, device="cuda"); nb = (n + bs - 1) // bs
-    table = eng.new_table(nb); index = eng.new_index(n, p)
+    table = eng.new_table(nb); index = torch.zeros(eng.index_size(n, p) * int(os.environ.get('IX_SCALE', '1')), dtype=torch.uint8, device='cuda')
     back = torch.empty_like(src)
     eng.set_timing(True)
     for it in range(3):
@@ -32,6 +32,9 @@ def run(src, label):
 good = True
 if kind == "synth50":
     good &= run(synth50_device(n, 1234), "synth50 %d MiB" % mib)
+elif kind == "text":
+    t = torch.from_numpy(datagen.synth_text(min(n, 64 << 20), 99)).cuda()
+    good &= run(t.repeat(max(1, n // t.numel())), "text %d MiB" % mib)
 else:
     for seed in range(int(kind)):
         a = np.frombuffer(datagen.structured(n, seed), dtype=np.uint8).copy()
