@@ -87,7 +87,8 @@ typedef std::conditional<(E1_TAG_BITS > 8), uint16_t, uint8_t>::type tag_t;
 // grid: one wave per chunk (blockDim = 64 * WAVES_PER_WG)
 template <int WAVES_PER_WG>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_t* __restrict__ src, EncGeom g,
-                                                                    ChunkInfo* __restrict__ info, uint64_t* __restrict__ recs)
+                                                                    ChunkInfo* __restrict__ info, uint64_t* __restrict__ recs,
+                                                                    unsigned long long* prof = nullptr)
 {
     __shared__ uint16_t s_table[WAVES_PER_WG][HASH_SIZE];
     __shared__ tag_t s_tag[WAVES_PER_WG][HASH_SIZE];        // TAG_BITS more hash bits per entry: filters false candidates without touching memory
@@ -138,6 +139,14 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
 
     uint32_t nrec = 0, first_lit = 0, body = 0;
     uint32_t anchor = cs;
+    // developer aid (-DE1_PROF, tools/e1_prof.py): cycles of one wave per phase of the search loop
+#ifdef E1_PROF
+    unsigned long long pt_probe = 0, pt_verify = 0, pt_ext = 0, pt_restart = 0, pn_iter = 0, pn_ver = 0;
+    const unsigned long long pt_begin = clock64();
+#define E1P(x) x
+#else
+#define E1P(x)
+#endif
     // a match may start at p iff p + 4 <= ce and p + MFLIMIT <= bend; it may end at min(ce, bend - LASTLIT).
     // Blocks shorter than MFLIMIT+1 bytes are literals only (Appendix A.2).
     const uint32_t blen = (uint32_t)(bend_abs - bstart), clen = ce - cs;
@@ -174,7 +183,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
             ipN = i_; stepN = st_;
         };
         fill_queue();
+        E1P(const unsigned long long pt_seeded = clock64();)
         while (ip <= last_start) {
+            E1P(__builtin_amdgcn_sched_barrier(0); const unsigned long long pq0 = clock64(); __builtin_amdgcn_sched_barrier(0); pn_iter++;)
             const uint32_t seqA = s0;
             // ---- probe A ----
             const uint32_t pA = ip + lane * step;
@@ -202,6 +213,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
             // the 64 bytes before and the 512 bytes from the probe position itself, on both sides; the candidate is a match
             // iff the first four bytes agree.  (A separate 4-byte gather first would cost a second trip on every match.)
             uint64_t cA = __ballot(okA), cB = __ballot(okB);
+            E1P(__builtin_amdgcn_sched_barrier(0); const unsigned long long pq1 = clock64(); __builtin_amdgcn_sched_barrier(0); pt_probe += pq1 - pq0; pn_ver += (cA | cB) ? 1 : 0;)
             bool hitB = false, found = false;
             uint32_t L = 0, mp = 0, mc = 0, dist = 0, room = 0;
             const uint32_t kb = lane + 1;
@@ -222,6 +234,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
                 if (a0 < end_lim) x0 = ld64_guard(base + a0, rd_end) ^ ld64_guard(base + (a0 - dist), rd_end);
                 if (__builtin_amdgcn_readlane((uint32_t)x0, 0) == 0) { found = true; break; }       // mp + 4 <= end_lim always
             }
+            E1P(__builtin_amdgcn_sched_barrier(0); const unsigned long long pq2 = clock64(); __builtin_amdgcn_sched_barrier(0); pt_verify += pq2 - pq1;)
             if (!found) {                                                           // both steps missed: advance two steps, top up the queue
                 ip = ipC; step = stepC;
                 s0 = s2; s1 = s3; s2 = s4; s3 = s5;
@@ -280,6 +293,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
                     mlen += WAVE * 8;
                 }
             }
+            E1P(__builtin_amdgcn_sched_barrier(0); const unsigned long long pq3 = clock64(); __builtin_amdgcn_sched_barrier(0); pt_ext += pq3 - pq2;)
             // append the sequence record (every lane stores the same 8 bytes: no lane-predicated branch in this loop)
             const uint32_t lit = mp - anchor;
             rec[nrec] = pack_rec(lit, mlen, dist);
@@ -295,7 +309,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
             const uint32_t v2 = ld32(base + q2);
             fill_queue();
             if (ins2) { const uint32_t hv = v2 * hmul; table[hv >> (32 - HASH_LOG)] = (uint16_t)q2; tags[hv >> (32 - HASH_LOG)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
+            E1P(__builtin_amdgcn_sched_barrier(0); pt_restart += clock64() - pq3; __builtin_amdgcn_sched_barrier(0);)
         }
+        E1P(if (prof && chunk == 1000 && lane == 0) { prof[64] = clock64() - pt_begin; prof[65] = pt_seeded - pt_begin; prof[66] = pt_probe; prof[67] = pt_verify; prof[68] = pt_ext; prof[69] = pt_restart; prof[70] = pn_iter; prof[71] = pn_ver; prof[72] = nrec; })
     }
     if (lane == 0) { ci->nrec = nrec; ci->first_lit = first_lit; ci->tail_lit = ce - anchor; ci->body_size = body; }
 }

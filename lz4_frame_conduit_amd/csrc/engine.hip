@@ -189,7 +189,7 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
         tick(0, false);
         constexpr int WF = 1;       // 12 KiB of LDS per wave: one-wave workgroups pack 13 waves into a CU's 160 KiB, four-wave ones 12
         hipLaunchKernelGGL((k_find_matches<WF>), dim3((g.n_chunks + WF - 1) / WF), dim3(64 * WF), 0, st, j.d_src, g,
-                           (ChunkInfo*)info.p, (uint64_t*)recs.p);
+                           (ChunkInfo*)info.p, (uint64_t*)recs.p, (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr));
         tick(0, true);
     }
     tick(1, false);
