@@ -67,6 +67,7 @@ __device__ __forceinline__ uint64_t pack_rec(uint32_t lit, uint32_t mlen, uint32
     return (uint64_t)lit | ((uint64_t)mlen << 24) | ((uint64_t)off << 48);
 }
 
+struct uint4_ua { uint32_t x, y, z, w; } __attribute__((packed, aligned(1)));
 __device__ __forceinline__ uint32_t ld32(const uint8_t* p) { return *(const u32_ua*)p; }
 typedef uint64_t u64_ua __attribute__((aligned(1)));
 // 8 bytes at p, never reading at or beyond `end`
@@ -116,6 +117,9 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
     const uint32_t bend = back + (uint32_t)(bend_abs - cs_abs);
     uint64_t* rec = recs + (uint64_t)chunk * g.max_rec_per_chunk;
 
+#ifdef E1_PROF
+    const unsigned long long pt_kernel = clock64();
+#endif
     // clear + pre-seed the table with the history in front of the chunk.  A 4096-entry table cannot hold
     // 64 KiB of positions, and later inserts win: seed the whole window sparsely (every SEED_STRIDE-th position,
     // roughly the density the skip-accelerated search itself leaves behind), then the last SEED_DENSE bytes densely.
@@ -124,16 +128,43 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
     if (back >= 4) {
         const uint32_t dense_from = back > g.seed_dense ? back - g.seed_dense : 0;
         const uint32_t ss = g.seed_stride;
-        for (uint32_t q = 0; q < dense_from; q += 4 * WAVE * ss) {                  // 4 loads in flight per wave
-            uint32_t pp[4], vv[4];
+        constexpr int SEED_IN_FLIGHT = 16;                                           // loads in flight per wave (registers are plentiful: LDS bounds the occupancy)
+        uint32_t q = 0;
+        if (ss == 4) {
+            // every 4th position: 16 bytes per lane hold four of them, a wave-load covers 1 KiB (a quarter of the load instructions)
+            const uint32_t span = dense_from & ~1023u;
+            for (; q < span; q += SEED_IN_FLIGHT * 1024) {
+                uint4 vv[SEED_IN_FLIGHT];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { pp[u] = q + (u * WAVE + lane) * ss; vv[u] = ld32(base + (pp[u] < dense_from ? pp[u] : 0u)); }
+                for (int u = 0; u < SEED_IN_FLIGHT; u++) { const uint32_t p = q + u * 1024 + lane * 16; const uint4_ua t = *(const uint4_ua*)(base + (p < span ? p : 0u)); vv[u] = uint4{t.x, t.y, t.z, t.w}; }
 #pragma unroll
-            for (int u = 0; u < 4; u++) if (pp[u] < dense_from) { const uint32_t hv = vv[u] * 2654435761u; table[hv >> (32 - HASH_LOG)] = (uint16_t)pp[u]; tags[hv >> (32 - HASH_LOG)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
+                for (int u = 0; u < SEED_IN_FLIGHT; u++) {
+                    const uint32_t p = q + u * 1024 + lane * 16;
+                    if (p < span) {
+                        const uint32_t w[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { const uint32_t hv = w[k] * 2654435761u; table[hv >> (32 - HASH_LOG)] = (uint16_t)(p + 4 * k); tags[hv >> (32 - HASH_LOG)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
+                    }
+                }
+            }
+            q = span;
         }
-        for (uint32_t q = dense_from; q + 4 <= back; q += WAVE) {
-            const uint32_t p = q + lane;
-            if (p + 4 <= back) { const uint32_t hv = ld32(base + p) * 2654435761u; table[hv >> (32 - HASH_LOG)] = (uint16_t)p; tags[hv >> (32 - HASH_LOG)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
+        for (; q < dense_from; q += SEED_IN_FLIGHT * WAVE * ss) {
+            uint32_t pp[SEED_IN_FLIGHT], vv[SEED_IN_FLIGHT];
+#pragma unroll
+            for (int u = 0; u < SEED_IN_FLIGHT; u++) { pp[u] = q + (u * WAVE + lane) * ss; vv[u] = ld32(base + (pp[u] < dense_from ? pp[u] : 0u)); }
+#pragma unroll
+            for (int u = 0; u < SEED_IN_FLIGHT; u++) if (pp[u] < dense_from) { const uint32_t hv = vv[u] * 2654435761u; table[hv >> (32 - HASH_LOG)] = (uint16_t)pp[u]; tags[hv >> (32 - HASH_LOG)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
+        }
+        for (uint32_t q = dense_from; q + 4 <= back; q += SEED_IN_FLIGHT * WAVE) {       // (inserted in position order: later ones win)
+            uint32_t vv[SEED_IN_FLIGHT];
+#pragma unroll
+            for (int u = 0; u < SEED_IN_FLIGHT; u++) { const uint32_t p = q + u * WAVE + lane; vv[u] = ld32(base + (p + 4 <= back ? p : 0u)); }
+#pragma unroll
+            for (int u = 0; u < SEED_IN_FLIGHT; u++) {
+                const uint32_t p = q + u * WAVE + lane;
+                if (p + 4 <= back) { const uint32_t hv = vv[u] * 2654435761u; table[hv >> (32 - HASH_LOG)] = (uint16_t)p; tags[hv >> (32 - HASH_LOG)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
+            }
         }
     }
 
@@ -277,19 +308,16 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
                 bool more = false;
                 if (stop0) { const uint32_t f = (uint32_t)__builtin_ctzll(stop0); mlen += f * 8 + __builtin_amdgcn_readlane(g0, f); }
                 else { mlen += WAVE * 8; more = true; }
-                while (more) {                                                      // long matches: keep going, two rounds per trip
-                    const uint32_t b0 = mp + mlen + lane * 8, b1 = b0 + WAVE * 8;
-                    uint64_t y0 = 0, y1 = 0;
+                while (more) {                                                      // long matches: keep going, 512 bytes per round
+                    // (one round per trip: hipcc waits for each of these guarded loads separately, so a second round fetched
+                    // "for free" cost two more round trips - and a match of exactly 512 bytes, the end of the first window, is common)
+                    const uint32_t b0 = mp + mlen + lane * 8;
+                    uint64_t y0 = 0;
                     if (b0 < end_lim) y0 = ld64_guard(base + b0, rd_end) ^ ld64_guard(base + (b0 - dist), rd_end);
-                    if (b1 < end_lim) y1 = ld64_guard(base + b1, rd_end) ^ ld64_guard(base + (b1 - dist), rd_end);
-                    uint32_t h0 = 0, h1 = 0;
+                    uint32_t h0 = 0;
                     if (b0 < end_lim) { h0 = y0 ? (uint32_t)(__builtin_ctzll(y0) >> 3) : 8; const uint32_t r = end_lim - b0; if (h0 > r) h0 = r; }
-                    if (b1 < end_lim) { h1 = y1 ? (uint32_t)(__builtin_ctzll(y1) >> 3) : 8; const uint32_t r = end_lim - b1; if (h1 > r) h1 = r; }
                     const uint64_t s0 = __ballot(h0 < 8);
                     if (s0) { const uint32_t f = (uint32_t)__builtin_ctzll(s0); mlen += f * 8 + __builtin_amdgcn_readlane(h0, f); break; }
-                    mlen += WAVE * 8;
-                    const uint64_t s1 = __ballot(h1 < 8);
-                    if (s1) { const uint32_t f = (uint32_t)__builtin_ctzll(s1); mlen += f * 8 + __builtin_amdgcn_readlane(h1, f); break; }
                     mlen += WAVE * 8;
                 }
             }
@@ -311,7 +339,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
             if (ins2) { const uint32_t hv = v2 * hmul; table[hv >> (32 - HASH_LOG)] = (uint16_t)q2; tags[hv >> (32 - HASH_LOG)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
             E1P(__builtin_amdgcn_sched_barrier(0); pt_restart += clock64() - pq3; __builtin_amdgcn_sched_barrier(0);)
         }
-        E1P(if (prof && chunk == 1000 && lane == 0) { prof[64] = clock64() - pt_begin; prof[65] = pt_seeded - pt_begin; prof[66] = pt_probe; prof[67] = pt_verify; prof[68] = pt_ext; prof[69] = pt_restart; prof[70] = pn_iter; prof[71] = pn_ver; prof[72] = nrec; })
+        E1P(if (prof && chunk == 1000 && lane == 0) { prof[64] = clock64() - pt_begin; prof[65] = pt_seeded - pt_begin; prof[66] = pt_probe; prof[67] = pt_verify; prof[68] = pt_ext; prof[69] = pt_restart; prof[70] = pn_iter; prof[71] = pn_ver; prof[72] = nrec; prof[73] = pt_begin - pt_kernel; })
     }
     if (lane == 0) { ci->nrec = nrec; ci->first_lit = first_lit; ci->tail_lit = ce - anchor; ci->body_size = body; }
 }

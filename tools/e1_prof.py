@@ -16,5 +16,5 @@ for _ in range(3):
 print("find_matches ms", eng.get_timing()["find_matches"])
 buf = (ctypes.c_ulonglong * 128)()
 ctypes.CDLL(_ffi.LIB_PATH).lz4f_mi355x_debug_prof(buf)
-names = ["total", "seed", "probe", "verify", "extend", "restart", "iterations", "iterations_with_candidates", "records"]
+names = ["total", "seed", "probe", "verify", "extend", "restart", "iterations", "iterations_with_candidates", "records", "clear_and_seed"]
 print({k: int(buf[64 + i]) for i, k in enumerate(names)})
