@@ -200,8 +200,12 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     tick(1, true);
     if (g.n_chunks) {
         tick(2, false);
-        hipLaunchKernelGGL((k_emit<W>), dim3((g.n_chunks + W - 1) / W), dim3(64 * W), 0, st, j.d_src, g, (const ChunkInfo*)info.p,
-                           (const uint64_t*)recs.p, d_dst, (const BlockOut*)d_table, d_index);
+        if (getenv("LZ4F_MI355X_EMIT_SERIAL"))                                  // the record-at-a-time kernel (same bytes)
+            hipLaunchKernelGGL((k_emit<W>), dim3((g.n_chunks + W - 1) / W), dim3(64 * W), 0, st, j.d_src, g, (const ChunkInfo*)info.p,
+                               (const uint64_t*)recs.p, d_dst, (const BlockOut*)d_table, d_index);
+        else
+            hipLaunchKernelGGL((k_emit_gather<W>), dim3((g.n_chunks + W - 1) / W), dim3(64 * W), 0, st, j.d_src, g, (const ChunkInfo*)info.p,
+                               (const uint64_t*)recs.p, d_dst, (const BlockOut*)d_table, d_index);
         tick(2, true);
         if (j.block_checksum) {
             tick(3, false);
