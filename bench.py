@@ -16,7 +16,8 @@ value = bytes of uncompressed input all ranks processed / max-over-ranks wall ti
 
 Extra objects on the JSON line:
   roofline     : the kernel with the largest share of the step, algorithmic bytes (U + C per direction,
-                 SURVEY.md section 8d) / its mean launch duration measured with HIP events on the launch stream
+                 SURVEY.md section 8d) / its launch duration measured with HIP events on the launch stream (the K steps of
+                 the timed region are enqueued back to back; the events read afterwards are those of the last of them)
   kernels      : the same for every kernel of the step
   cpu_baseline : the same blocks through liblz4 (dlopen, kind "reference") or the oracle port, on the host cores,
                  rank 0 at N=1 only, on a bounded sample
@@ -145,18 +146,17 @@ def main():
     r = eng.result()
     csize = int(r.size)
 
-    kt = {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        if rank == 0:
-            # get_timing synchronises the stream; the same sync would be paid by the next step's barrier anyway
-            for k, v in eng.get_timing().items():
-                kt.setdefault(k, []).append(v)
+        step()                                                # enqueue only: nothing in the timed region waits for the host
     barrier()
     dt = time.perf_counter() - t0
     dt = shard.max_over_ranks(dt, dev)
+    kt = {}
+    if rank == 0:                                             # per-kernel HIP-event times of the last timed step (the events are recorded
+        for k, v in eng.get_timing().items():                 # on the launch stream in every step; reading them is what would synchronise)
+            kt.setdefault(k, []).append(v)
     r2 = eng.result()
     ok = bool(r2.size == n and torch.equal(back, src))
     generic_ms = None

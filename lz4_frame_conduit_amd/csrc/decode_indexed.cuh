@@ -44,16 +44,32 @@ __device__ __forceinline__ void pt_load16(const uint8_t* __restrict__ in, uint32
     lo = pt_load8(in, pos, readable); hi = pt_load8(in, pos + 8, readable);
 }
 
+// The index header is checked on the device (no host round trip on this path): usable at all, made for this geometry, its
+// tables inside the buffer the caller named, its sequences inside the descriptor workspace the engine has.  flags[0] != 0
+// sends the call to the generic decoder; flags[8] / flags[9] carry the entry and sequence counts to the kernels behind.
+__global__ void k_check_index(const void* __restrict__ ix, uint64_t ix_size, uint32_t n_blocks, uint32_t chunks_per_block, uint32_t chunk_size,
+                              uint64_t seq_cap, uint32_t* __restrict__ flags)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const IxHeader hd = *(const IxHeader*)ix;
+    const bool ok = hd.magic == IX_MAGIC && hd.n_blocks == n_blocks && hd.chunks_per_block == chunks_per_block && hd.stride == IX_STRIDE &&
+                    hd.total_entries <= (uint64_t)n_blocks * chunks_per_block * ix_max_entries_per_chunk(chunk_size) &&
+                    hd.total_seqs <= (uint64_t)hd.total_entries * (IX_STRIDE + 1) && hd.total_seqs <= seq_cap &&
+                    ix_entries_at(n_blocks, chunks_per_block) + (uint64_t)hd.total_entries * sizeof(IxEntry) <= ix_size;
+    flags[8] = ok ? hd.total_entries : 0u;
+    flags[9] = ok ? hd.total_seqs : 0u;
+    if (!ok) atomicOr(flags, 1u);
+}
+
 // k_parse_indexed, one lane per index entry.  (The index structures and k_build_index live in encode.cuh: pass E2 writes the entries.)
 // Input-side rules only (the feeder wave checks the ones that need output positions).  `flags[0]` is set when anything
 // disagrees with the index: the caller then falls back to the generic decoder.  Every entry must end exactly where the next
 // one starts and the first one of a block at payload byte 0, so the descriptors are a complete parse of the payload itself:
 // a wrong index can make the call fall back, never change the bytes that come out.
-__global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
-                                                       const void* __restrict__ ix, uint32_t n_blocks, uint32_t n_entries,
-                                                       SeqDesc* __restrict__ desc, uint64_t desc_cap, uint32_t* __restrict__ flags)
+__device__ __forceinline__ void parse_entry(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
+                                            const void* __restrict__ ix, uint32_t n_blocks, uint32_t n_entries,
+                                            SeqDesc* __restrict__ desc, uint64_t desc_cap, uint32_t* __restrict__ flags, uint32_t gid)
 {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const IxBlock* blocks = ix_blocks(ix);
     if (gid < n_blocks) {
         // the block table must hand out the descriptors and the entries without gaps or overlaps (every descriptor is then
@@ -156,6 +172,19 @@ __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict
     if (bad) atomicOr(flags, 1u);
 }
 
+__global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
+                                                       const void* __restrict__ ix, uint32_t n_blocks,
+                                                       SeqDesc* __restrict__ desc, uint32_t* __restrict__ flags)
+{
+    if (*flags) return;
+    const uint32_t n_entries = flags[8];
+    const uint64_t desc_cap = flags[9];
+    const uint32_t n_lanes = n_entries > n_blocks ? n_entries : n_blocks;
+    for (uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n_lanes; gid += gridDim.x * blockDim.x)
+        parse_entry(frame, frame_cap, table, ix, n_blocks, n_entries, desc, desc_cap, flags, gid);
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // One lane per sequence: where in the PAYLOAD do the bytes of my match come from?  The lane looks up the sequence that
 // produced its first source byte (binary search over the block's descriptors, which are sorted by output position).  Inside
@@ -165,10 +194,11 @@ __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict
 constexpr uint32_t IXR_HOPS = 6;
 constexpr uint32_t IX_NOT_DIRECT = 0xFFFFFFFFu;
 __global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, const ResultRec* __restrict__ res, uint32_t n_max,
-                                                        const SeqDesc* __restrict__ desc, uint32_t* __restrict__ dsrc, uint64_t desc_cap,
+                                                        const SeqDesc* __restrict__ desc, uint32_t* __restrict__ dsrc,
                                                         uint32_t* __restrict__ flags, uint32_t count_it)
 {
     if (res->status != ST_OK || *flags) return;
+    const uint64_t desc_cap = flags[9];
     const uint32_t b = blockIdx.y;
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
     if (b >= n) return;

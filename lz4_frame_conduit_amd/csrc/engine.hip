@@ -122,6 +122,8 @@ lz4f_mi355x_engine::~lz4f_mi355x_engine()
     d_in.release(); d_out.release();
     h_in.release(); h_out.release(); h_small.release();
     for (int i = 0; i < 20; i++) if (ev[i]) (void)hipEventDestroy((hipEvent_t)ev[i]);
+    if (ix_ev) (void)hipEventDestroy((hipEvent_t)ix_ev);
+    h_ix.release();
     if (own_stream && stream) (void)hipStreamDestroy((hipStream_t)stream);
 }
 
@@ -261,29 +263,43 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         if (const char* dv = getenv("LZ4F_MI355X_DECODE")) mode = dv[0];
         bool indexed = false;
         if (mode == 'f' && j.d_index && j.index_size >= sizeof(IxHeader) && !j.linked && !getenv("LZ4F_MI355X_NO_INDEX")) {
-            // descriptors from the compressor's sequence index: a lane per entry parses, a workgroup per block copies out of an
-            // LDS window.  The index header (16 bytes) is read back to size the descriptor workspace: the one host sync here.
-            IxHeader hd; memset(&hd, 0, sizeof(hd));
-            HIP_TRY(hipMemcpyAsync(&hd, j.d_index, sizeof(hd), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            // Descriptors from the compressor's sequence index: a lane per entry parses, a lane per sequence resolves direct
+            // matches, a workgroup per block copies.  The descriptor workspace is sized from the index header.  The first
+            // call reads it back (a host synchronisation); every call leaves a copy of its header in pinned memory behind the
+            // kernels, and the next one sizes from that - the device checks that the workspace is big enough for the index it
+            // actually gets (k_check_index) and otherwise hands the call to the generic decoder.
             const uint32_t chunk = pick_chunk_size(j.block_size), cpb = j.block_size / chunk;
-            if (hd.magic == IX_MAGIC && hd.n_blocks == n_max && hd.chunks_per_block == cpb && hd.stride == IX_STRIDE &&
-                hd.total_entries <= (uint64_t)n_max * cpb * ix_max_entries_per_chunk(chunk) && hd.total_seqs <= (uint64_t)hd.total_entries * (IX_STRIDE + 1) &&
-                ix_entries_at(n_max, cpb) + (uint64_t)hd.total_entries * sizeof(IxEntry) <= j.index_size) {
-                const size_t dsrc_at = ((size_t)hd.total_seqs + 64) * sizeof(SeqDesc);
-                if (desc.ensure(dsrc_at + ((size_t)hd.total_seqs + 64) * 4) || seqcnt.ensure(256)) return make_err(LZ4F_ERROR_allocation_failed);
-                HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 32, st));
-                const uint32_t n_entries = hd.total_entries;
-                const uint32_t n_lanes = n_entries > n_max ? n_entries : n_max;
+            if (h_ix.ensure(64)) return make_err(LZ4F_ERROR_allocation_failed);
+            if (!ix_ev) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ix_ev = e; }
+            IxHeader hd; memset(&hd, 0, sizeof(hd));
+            bool have = false;
+            if (ix_pending && hipEventQuery((hipEvent_t)ix_ev) == hipSuccess) { memcpy(&hd, h_ix.p, sizeof(hd)); ix_pending = false; have = true; }
+            if (!have && ix_seq_cap == 0) {
+                HIP_TRY(hipMemcpyAsync(&hd, j.d_index, sizeof(hd), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                have = true;
+            }
+            if (have && hd.magic == IX_MAGIC && hd.stride == IX_STRIDE && hd.total_seqs <= (uint64_t)hd.total_entries * (IX_STRIDE + 1) &&
+                hd.total_entries <= (j.index_size - sizeof(IxHeader)) / sizeof(IxEntry)) {
+                if (hd.total_seqs > ix_seq_cap) ix_seq_cap = (size_t)hd.total_seqs + hd.total_seqs / 4 + 4096;      // (a quarter of slack: the next stream differs)
+                if (hd.total_entries > ix_entries_hint) ix_entries_hint = hd.total_entries + hd.total_entries / 4;
+            }
+            if (ix_seq_cap) {
+                const size_t dsrc_at = (ix_seq_cap + 64) * sizeof(SeqDesc);
+                if (desc.ensure(dsrc_at + (ix_seq_cap + 64) * 4) || seqcnt.ensure(256)) return make_err(LZ4F_ERROR_allocation_failed);
+                HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 64, st));
                 unsigned long long* iprof = (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr);
                 tick(8, false);
+                hipLaunchKernelGGL(k_check_index, dim3(1), dim3(64), 0, st, (const void*)j.d_index, (uint64_t)j.index_size, n_max, cpb, chunk,
+                                   (uint64_t)ix_seq_cap, (uint32_t*)seqcnt.p);
+                uint32_t n_lanes = ix_entries_hint > n_max ? ix_entries_hint : n_max;           // (grid-stride inside: a hint is enough)
                 hipLaunchKernelGGL(k_parse_indexed, dim3((n_lanes + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap,
-                                   (const BlockOut*)tbl, (const void*)j.d_index, n_max, n_entries, (SeqDesc*)desc.p, (uint64_t)hd.total_seqs, (uint32_t*)seqcnt.p);
+                                   (const BlockOut*)tbl, (const void*)j.d_index, n_max, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p);
                 uint32_t* dsrc = (uint32_t*)((uint8_t*)desc.p + dsrc_at);
                 if (getenv("LZ4F_MI355X_NO_RESOLVE")) dsrc = nullptr;
                 else
                     hipLaunchKernelGGL(k_resolve_direct, dim3(j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u, n_max), dim3(256), 0, st, j.d_index, (const ResultRec*)d_res, n_max, (const SeqDesc*)desc.p,
-                                       dsrc, (uint64_t)hd.total_seqs, (uint32_t*)seqcnt.p, iprof ? 1u : 0u);
+                                       dsrc, (uint32_t*)seqcnt.p, iprof ? 1u : 0u);
                 if (iprof) {                                                   // developer aid: how many matches are direct
                     uint32_t c[8];
                     if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(c, seqcnt.p, 32, hipMemcpyDeviceToHost) == hipSuccess)
@@ -300,6 +316,10 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 tick(9, true);
                 indexed = true;
             }
+            // this call's header for the next call (no wait here)
+            HIP_TRY(hipMemcpyAsync(h_ix.p, j.d_index, sizeof(IxHeader), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipEventRecord((hipEvent_t)ix_ev, st));
+            ix_pending = true;
         }
         if (mode == 'f') {
             unsigned long long* prof = (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr);

@@ -56,6 +56,8 @@ struct lz4f_mi355x_engine {
     lz4f::DevBuf desc, seqcnt;                             // two-kernel decode: sequence descriptors, per-block counts
     lz4f::DevBuf d_in, d_out;                              // staging for the host-pointer paths
     lz4f::PinBuf h_in, h_out, h_small;
+    // indexed decode: the last index header seen (copied back asynchronously) sizes the descriptor workspace of the next call
+    lz4f::PinBuf h_ix; void* ix_ev = nullptr; bool ix_pending = false; size_t ix_seq_cap = 0; uint32_t ix_entries_hint = 0;
     bool  timing = false;
     void* ev[20] = {nullptr};      // hipEvent_t pairs (begin,end) per timing slot
     bool  ev_used[10] = {false};
