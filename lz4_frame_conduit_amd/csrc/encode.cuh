@@ -438,6 +438,117 @@ __global__ __launch_bounds__(1024) void k_layout(EncGeom g, ChunkInfo* __restric
     if (!fits) for (uint32_t c = t; c < g.n_chunks; c += 1024) info[c].flags |= 4u;   // tell pass E2 to do nothing
 }
 
+// ------------------------------- pass S spread over the machine --------------------------------
+// k_layout does everything from one workgroup: with 32 k chunks that is ~100 k memory requests through one CU (0.1 ms).
+// The same steps as three launches: per block on a wave (chunks in the lanes, carries and offsets by prefix sums),
+// the scan over the blocks on one workgroup, the per-chunk fix-up on a thread per chunk.  Same results (tools/emit_compare.py).
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t& total)
+{
+    const uint32_t lane = lane_id();
+    uint32_t incl = v;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t t = __shfl_up(incl, sft); if ((int)lane >= sft) incl += t; }
+    total = __builtin_amdgcn_readlane(incl, 63);
+    return incl - v;
+}
+
+template <int WAVES_PER_WG>
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void k_layout_blocks(EncGeom g, ChunkInfo* __restrict__ info, BlockOut* __restrict__ table,
+                                                                     uint32_t* __restrict__ blk_bytes)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t b = uni(blockIdx.x * WAVES_PER_WG + (threadIdx.x >> 6));
+    if (b >= g.n_blocks) return;
+    const uint64_t bstart = g.first_off + (uint64_t)b * g.block_size;
+    const uint32_t blen = (uint32_t)((bstart + g.block_size < g.src_size) ? g.block_size : g.src_size - bstart);
+    ChunkInfo* ci = info + (uint64_t)b * g.chunks_per_block;
+    const uint32_t nch = (blen + g.chunk_size - 1) / g.chunk_size;
+    uint32_t carry_run = 0, total = 0;                      // literals pending from the groups before; payload bytes so far
+    for (uint32_t c0 = 0; c0 < nch; c0 += WAVE) {
+        const uint32_t c = c0 + lane;
+        const bool act = c < nch;
+        const uint4 x = act ? *(const uint4*)&ci[c] : uint4{0u, 0u, 0u, 0u};       // {nrec, first_lit, tail_lit, body_size}
+        const bool has = act && x.x != 0;
+        const uint64_t m = __ballot(has);
+        uint32_t sum_tail, sum_size;
+        const uint32_t pt = wave_excl_scan(act ? x.z : 0u, sum_tail);
+        const uint64_t below = m & ((1ull << lane) - 1ull);
+        const uint32_t p = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;   // the chunk with records before me in this group
+        const uint32_t pt_p = __shfl(pt, (int)p);
+        const uint32_t carry = below ? pt - pt_p : carry_run + pt;                // its tail and every tail since, or all tails since the group began
+        const uint32_t size = has ? x.w + carry + len_ext_bytes(x.y + carry) - len_ext_bytes(x.y) : 0u;
+        const uint32_t off = wave_excl_scan(size, sum_size);
+        if (act) {
+            *(uint2*)&ci[c].carry_in = uint2{carry, (c + 1 == nch) ? 2u : 0u};       // carry_in, flags
+            ci[c].out_off = total + off;                    // relative for now
+        }
+        if (m) { const uint32_t last = 63u - (uint32_t)__builtin_clzll(m); carry_run = sum_tail - (uint32_t)__shfl(pt, (int)last); }
+        else carry_run += sum_tail;
+        total += sum_size;
+    }
+    total += 1 + len_ext_bytes(carry_run) + carry_run;      // final literal-only sequence
+    const bool raw = total >= blen;                         // LZ4F stores raw when it does not fit blockSize-1
+    if (raw) for (uint32_t c = lane; c < nch; c += WAVE) ci[c].flags = ((c + 1 == nch) ? 2u : 0u) | 1u;
+    if (lane == 0) {
+        table[b].word = raw ? (blen | 0x80000000u) : total;
+        table[b].dst_off = bstart - g.first_off;
+        table[b].dst_size = blen;
+        blk_bytes[b] = 4 + (raw ? blen : total) + 4 * g.block_checksum;
+    }
+}
+
+// the scan over the blocks, header, EndMark, result record (one workgroup)
+__global__ __launch_bounds__(1024) void k_layout_scan(EncGeom g, BlockOut* __restrict__ table, const uint32_t* __restrict__ blk_bytes,
+                                                      uint8_t* __restrict__ dst, uint64_t dst_cap, ResultRec* __restrict__ res)
+{
+    __shared__ uint64_t s_part[1024];
+    __shared__ uint64_t s_carry;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) s_carry = g.header_size;
+    __syncthreads();
+    for (uint32_t base = 0; base < g.n_blocks; base += 1024) {
+        const uint32_t b = base + t;
+        const uint64_t v = (b < g.n_blocks) ? blk_bytes[b] : 0;
+        s_part[t] = v;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            uint64_t add = (t >= off) ? s_part[t - off] : 0;
+            __syncthreads();
+            s_part[t] += add;
+            __syncthreads();
+        }
+        if (b < g.n_blocks) table[b].src_off = s_carry + s_part[t] - v + 4;       // payload follows the size word
+        __syncthreads();
+        if (t == 1023) s_carry += s_part[1023];
+        __syncthreads();
+    }
+    const uint64_t frame_size = s_carry + (g.write_endmark ? 4 : 0);
+    const bool fits = frame_size <= dst_cap;
+    if (fits) {
+        if (t < g.header_size) dst[t] = g.header[t];
+        if (t < 4 && g.write_endmark) dst[s_carry + t] = 0;
+    }
+    if (t == 0 && res) {
+        res->size = fits ? frame_size : 0; res->consumed = g.src_size - g.first_off;
+        res->status = fits ? ST_OK : ST_DSTSMALL; res->n_blocks = g.n_blocks; res->first_bad_block = 0xFFFFFFFFu; res->flags = g.header[4];
+    }
+}
+
+// a thread per chunk: absolute offsets; the first chunk of a block writes the block's size word
+__global__ __launch_bounds__(256) void k_layout_chunks(EncGeom g, ChunkInfo* __restrict__ info, const BlockOut* __restrict__ table,
+                                                       uint8_t* __restrict__ dst, const ResultRec* __restrict__ res)
+{
+    const uint32_t chunk = blockIdx.x * 256 + threadIdx.x;
+    if (chunk >= g.n_chunks) return;
+    if (res->status != ST_OK) { info[chunk].flags |= 4u; return; }               // does not fit: pass E2 does nothing
+    const uint32_t b = chunk / g.chunks_per_block, c = chunk % g.chunks_per_block;
+    const BlockOut e = table[b];
+    const uint32_t nch = (e.dst_size + g.chunk_size - 1) / g.chunk_size;
+    if (c == 0) { const uint32_t w = e.word; uint8_t* q = dst + e.src_off - 4; q[0] = (uint8_t)w; q[1] = (uint8_t)(w >> 8); q[2] = (uint8_t)(w >> 16); q[3] = (uint8_t)(w >> 24); }
+    if (c >= nch) return;
+    info[chunk].out_off = (e.word >> 31) ? e.src_off + (uint64_t)c * g.chunk_size : e.src_off + info[chunk].out_off;
+}
+
 // ------------------------------- sequence index (optional) -------------------------------------
 // A side table for this library's own decoder (decode_indexed.cuh): an entry point into the block's payload every IX_STRIDE
 // sequences -- where the token sits, which output position the sequence starts at.  The frame does not change.
@@ -468,8 +579,40 @@ __device__ __forceinline__ const IxEntry* ix_entries(const void* ix, uint32_t n_
     return (const IxEntry*)((const uint8_t*)ix + ix_entries_at(n_blocks, ((const IxHeader*)ix)->chunks_per_block));
 }
 
+// per block on a wave (chunks in the lanes): the part of k_build_index that walks the chunks
+template <int WAVES_PER_WG>
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void k_index_blocks(EncGeom g, const ChunkInfo* __restrict__ info, const BlockOut* __restrict__ table,
+                                                                    const ResultRec* __restrict__ res, void* __restrict__ ix, uint64_t ix_capacity)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t b = uni(blockIdx.x * WAVES_PER_WG + (threadIdx.x >> 6));
+    if (b >= g.n_blocks || ix_capacity < ix_entries_at(g.n_blocks, g.chunks_per_block)) return;
+    IxBlock* blocks = ix_blocks(ix);
+    IxChunk* ck = ix_chunks(ix, g.n_blocks) + (uint64_t)b * g.chunks_per_block;
+    const bool usable = res->status == ST_OK && !g.linked;
+    const BlockOut e = table[b];
+    const ChunkInfo* ci = info + (uint64_t)b * g.chunks_per_block;
+    const uint32_t nch = (e.dst_size + g.chunk_size - 1) / g.chunk_size;
+    uint32_t nseq = 0, nent = 0, last = 0xFFFFFFFFu;
+    for (uint32_t c0 = 0; c0 < g.chunks_per_block; c0 += WAVE) {
+        const uint32_t c = c0 + lane;
+        const uint32_t nr = (c < nch && usable && !(e.word >> 31)) ? ci[c].nrec : 0u;
+        uint32_t ts, te;
+        const uint32_t ps = wave_excl_scan(nr, ts), pe = wave_excl_scan((nr + IX_STRIDE - 1) / IX_STRIDE, te);
+        if (c < g.chunks_per_block) ck[c] = IxChunk{nent + pe, nseq + ps};
+        const uint64_t m = __ballot(nr != 0);
+        if (m) last = c0 + 63u - (uint32_t)__builtin_clzll(m);
+        nseq += ts; nent += te;
+    }
+    if (lane == 0) {
+        if (last != 0xFFFFFFFFu) { ck[last].ent_off |= 0x80000000u; nseq += 1; }     // the block's final literal-only sequence
+        blocks[b].nseq = nseq; blocks[b].nentries = nent;
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_build_index(EncGeom g, const ChunkInfo* __restrict__ info, const BlockOut* __restrict__ table,
-                                                      const ResultRec* __restrict__ res, void* __restrict__ ix, uint64_t ix_capacity)
+                                                      const ResultRec* __restrict__ res, void* __restrict__ ix, uint64_t ix_capacity,
+                                                      uint32_t blocks_done = 0)
 {
     __shared__ uint32_t s_a[1024], s_b[1024];
     __shared__ uint32_t s_carry_a, s_carry_b;
@@ -480,8 +623,8 @@ __global__ __launch_bounds__(1024) void k_build_index(EncGeom g, const ChunkInfo
     const size_t fixed = ix_entries_at(g.n_blocks, g.chunks_per_block);
     if (ix_capacity < fixed) { if (t == 0 && ix_capacity >= sizeof(IxHeader)) hd->magic = 0; return; }
     const bool usable = res->status == ST_OK && !g.linked;
-    // 1) per block: its chunks in order
-    for (uint32_t b = t; b < g.n_blocks; b += 1024) {
+    // 1) per block: its chunks in order (unless k_index_blocks did that already)
+    for (uint32_t b = t; b < g.n_blocks && !blocks_done; b += 1024) {
         const BlockOut e = table[b];
         const ChunkInfo* ci = info + (uint64_t)b * g.chunks_per_block;
         IxChunk* ck = chunks + (uint64_t)b * g.chunks_per_block;

@@ -15,18 +15,19 @@ def one(src, bsid, indep, label):
     bs = 1 << (8 + 2 * bsid); nb = (src.numel() + bs - 1) // bs
     out = []
     for serial in (True, False):
-        if serial: os.environ["LZ4F_MI355X_EMIT_SERIAL"] = "1"
-        else: os.environ.pop("LZ4F_MI355X_EMIT_SERIAL", None)
+        for k in ("LZ4F_MI355X_EMIT_SERIAL", "LZ4F_MI355X_LAYOUT_SERIAL"):
+            if serial: os.environ[k] = "1"
+            else: os.environ.pop(k, None)
         frame = torch.zeros(eng.frame_bound(src.numel(), p), dtype=torch.uint8, device="cuda")
         table = eng.new_table(nb); index = torch.zeros(eng.index_size(src.numel(), p) * 16, dtype=torch.uint8, device="cuda")
         eng.compress_async(src, frame, p, table, index); r = eng.result()
-        out.append((frame, index, r.size, eng.get_timing()["emit"]))
-    same = out[0][2] == out[1][2] and torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+        out.append((frame, index, r.size, eng.get_timing()["emit"], eng.get_timing()["layout"], table.clone()))
+    same = out[0][2] == out[1][2] and torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][5][:nb * 24], out[1][5][:nb * 24])
     if not same:
         bad += 1
         d = (out[0][0] != out[1][0]).nonzero()
         print("DIFF", label, "sizes", out[0][2], out[1][2], "first frame diff", int(d[0]) if len(d) else None, "index equal", bool(torch.equal(out[0][1], out[1][1])), flush=True)
-    return out[0][3], out[1][3]
+    return (out[0][3], out[0][4]), (out[1][3], out[1][4])
 for i in range(cases):
     kind = int(rng.integers(0, 4)); n = int(rng.integers(1, 24 << 20))
     if kind == 0: data = np.frombuffer(datagen.structured(n, int(rng.integers(1 << 30))), dtype=np.uint8).copy()
@@ -37,7 +38,8 @@ for i in range(cases):
 print("cases", cases, "differences", bad)
 for name, src in (("synth50 4 GiB", synth50_device(4 << 30, 1234)),):
     a, b = one(src, 7, 1, name)
-    print(name, "emit ms serial %.3f gather %.3f" % (a, b))
+    print(name, "emit/layout ms serial %.3f %.3f  new %.3f %.3f" % (a + b))
 t = torch.from_numpy(datagen.synth_text(64 << 20, 99)).cuda().repeat(16)
-a, b = one(t, 7, 1, "text 1 GiB"); print("text 1 GiB emit ms serial %.3f gather %.3f" % (a, b))
+a, b = one(t, 7, 1, "text 1 GiB"); print("text 1 GiB emit/layout ms serial %.3f %.3f  new %.3f %.3f" % (a + b))
+a, b = one(t[: (64 << 20) + 12345], 4, 1, "text 64 KiB blocks"); print("text 64 MiB, 64 KiB blocks: emit/layout ms serial %.3f %.3f  new %.3f %.3f" % (a + b))
 sys.exit(1 if bad else 0)
