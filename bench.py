@@ -50,7 +50,7 @@ def pmc_traffic(kernel: str, n_bytes: int, block_size: int, indexed: bool = True
                 return int(json.load(f)["kernels"]["k_decode_blocks_fused<lz4f::FzCfg<8> >"]["hbm_bytes_corrected"])
         with open(os.path.join(ROOT, "profiles", "round1b_pmc_traffic.json")) as f:
             prof = json.load(f)
-        names = {"find_matches": ["k_find_matches<1>"], "emit": ["k_emit<4>"],
+        names = {"find_matches": ["k_find_matches<1>"], "emit": ["k_emit_gather<4>"],
                  "decode": ["k_parse_indexed", "k_resolve_direct", "k_copy_indexed<FzCfg<8> >"]}
         return int(sum(prof["kernels"][k]["hbm_bytes_corrected"] for k in names[kernel]))
     except Exception:

@@ -235,10 +235,10 @@ LZ4F_MI355X_API size_t lz4f_mi355x_dev_decompressBlocks(lz4f_mi355x_engine* e, v
                                                         const LZ4F_frameInfo_t* info, lz4f_mi355x_result* d_result);
 
 /* Sequence index (optional side channel between this library's own compress and decompress; the frame itself stays a
- * plain LZ4 frame and decodes without it).  The compressor works on 128 KiB chunks and knows, for each, where its first
- * token sits in the block's payload, which output position that sequence starts at and how many sequences follow;
- * with that table the decoder parses every chunk on its own lane and replays the copies out of an on-chip window
- * instead of walking one dependent chain per 4 MiB block (replaces the same inner loop of LZ4F_decompress,
+ * plain LZ4 frame and decodes without it).  While it writes a block's payload the compressor notes, every 16 sequences,
+ * where the token sits in the payload and which output position the sequence starts at; with that table the decoder
+ * parses every 16 sequences on their own lane, finds the matches whose bytes sit in the payload itself, and copies in
+ * parallel instead of walking one dependent chain per 4 MiB block (replaces the same inner loop of LZ4F_decompress,
  * Conduit.hsc:591).  The decoder still parses the payload itself -- the index only says where it may start -- and checks
  * that the pieces join up: a missing, stale or foreign index makes it fall back to the generic decoder, it cannot change
  * the bytes that come out.  Independent blocks only.  A stream with more sequences than the index has room for (about one

@@ -3,12 +3,12 @@
 //
 // The scalar parser of decode_fused.cuh costs ~200 scalar instructions per sequence and a CU has one scalar unit:
 // however the waves are arranged, the GPU parses the headline workload in >= 2 ms.  A lane-per-entry walk of the same
-// chains needs entry points.  The compressor has them for free: pass E1 works on 128 KiB chunks, so for every chunk
-// that found matches pass S knows where its first token sits in the block's payload, which output position that
-// sequence starts at, and how many sequences follow until the next such chunk.  That table (16 bytes per chunk) is the
-// index; frames stay plain LZ4 frames, and a frame without an index (or with one that does not fit) is decoded by the
-// generic kernels.
-//   k_build_index     (compress side, after k_layout) entries per chunk, descriptor base per block, total count
+// chains needs entry points.  The compressor has them: pass E2 walks the records with both positions at hand and notes,
+// every 16 sequences, where the token sits in the block's payload and which output position the sequence starts at.
+// That table (16 bytes per 16 sequences) is the index; frames stay plain LZ4 frames, and a frame without an index (or
+// with one that does not fit) is decoded by the generic kernels.
+//   k_index_blocks / k_build_index / pass E2 (compress side, encode.cuh)  the index
+//   k_check_index     the index header against this call's geometry, buffer and workspace (on the device)
 //   k_parse_indexed   one LANE per entry: walks its sequences in the payload and writes 16-byte descriptors
 //                     {literal source, literal length, output position, match length, offset} to HBM; checks that
 //                     it ends exactly where the next entry starts (else the index is declared unusable)
