@@ -27,7 +27,17 @@
 namespace lz4f {
 
 constexpr uint32_t HASH_LOG = 12;
-constexpr uint32_t HASH_SIZE = 1u << HASH_LOG;          // entries (u16) per wave
+#ifndef E1_TABLE_SIXTEENTHS
+#define E1_TABLE_SIXTEENTHS 15
+#endif
+// entries per wave.  (E1_TABLE_SIXTEENTHS / 16 of 2^HASH_LOG: the table is what bounds the waves per CU - 15/16 of 4096
+// entries at 3 bytes is 11.25 KiB, 14 waves in a CU's 160 KiB instead of 13.)
+constexpr uint32_t HASH_SIZE = (E1_TABLE_SIXTEENTHS << HASH_LOG) >> 4;
+__device__ __forceinline__ uint32_t hash_slot(uint32_t hv)
+{
+    const uint32_t top = hv >> (32 - HASH_LOG);
+    return E1_TABLE_SIXTEENTHS == 16 ? top : (top * E1_TABLE_SIXTEENTHS) >> 4;
+}
 constexpr uint32_t MFLIMIT = 12, LASTLIT = 5, MINMATCH = 4;
 
 struct ChunkInfo {           // 32 bytes, one per chunk
@@ -143,7 +153,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
                     if (p < span) {
                         const uint32_t w[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
 #pragma unroll
-                        for (int k = 0; k < 4; k++) { const uint32_t hv = w[k] * 2654435761u; table[hv >> (32 - HASH_LOG)] = (uint16_t)(p + 4 * k); tags[hv >> (32 - HASH_LOG)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
+                        for (int k = 0; k < 4; k++) { const uint32_t hv = w[k] * 2654435761u; table[hash_slot(hv)] = (uint16_t)(p + 4 * k); tags[hash_slot(hv)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
                     }
                 }
             }
@@ -154,7 +164,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
 #pragma unroll
             for (int u = 0; u < SEED_IN_FLIGHT; u++) { pp[u] = q + (u * WAVE + lane) * ss; vv[u] = ld32(base + (pp[u] < dense_from ? pp[u] : 0u)); }
 #pragma unroll
-            for (int u = 0; u < SEED_IN_FLIGHT; u++) if (pp[u] < dense_from) { const uint32_t hv = vv[u] * 2654435761u; table[hv >> (32 - HASH_LOG)] = (uint16_t)pp[u]; tags[hv >> (32 - HASH_LOG)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
+            for (int u = 0; u < SEED_IN_FLIGHT; u++) if (pp[u] < dense_from) { const uint32_t hv = vv[u] * 2654435761u; table[hash_slot(hv)] = (uint16_t)pp[u]; tags[hash_slot(hv)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
         }
         for (uint32_t q = dense_from; q + 4 <= back; q += SEED_IN_FLIGHT * WAVE) {       // (inserted in position order: later ones win)
             uint32_t vv[SEED_IN_FLIGHT];
@@ -163,7 +173,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
 #pragma unroll
             for (int u = 0; u < SEED_IN_FLIGHT; u++) {
                 const uint32_t p = q + u * WAVE + lane;
-                if (p + 4 <= back) { const uint32_t hv = vv[u] * 2654435761u; table[hv >> (32 - HASH_LOG)] = (uint16_t)p; tags[hv >> (32 - HASH_LOG)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
+                if (p + 4 <= back) { const uint32_t hv = vv[u] * 2654435761u; table[hash_slot(hv)] = (uint16_t)p; tags[hash_slot(hv)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
             }
         }
     }
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
             // ---- probe A ----
             const uint32_t pA = ip + lane * step;
             const bool actA = pA <= last_start;
-            const uint32_t hvA = seqA * hmul, hA = hvA >> (32 - HASH_LOG), tgA = (hvA >> (32 - TAG_BITS - HASH_LOG)) & TAG_MASK;
+            const uint32_t hvA = seqA * hmul, hA = hash_slot(hvA), tgA = (hvA >> (32 - TAG_BITS - HASH_LOG)) & TAG_MASK;
             uint32_t eA = 0, tA = TAG_MASK + 1;
             if (actA) { eA = table[hA]; tA = tags[hA]; table[hA] = (uint16_t)pA; tags[hA] = (tag_t)tgA; }
             const uint32_t dA = (pA - eA) & 0xFFFFu;
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
             const uint32_t seqB = s1;
             const uint32_t pB = ipB + lane * stepB;
             const bool actB = pB <= last_start;
-            const uint32_t hvB = seqB * hmul, hB = hvB >> (32 - HASH_LOG), tgB = (hvB >> (32 - TAG_BITS - HASH_LOG)) & TAG_MASK;
+            const uint32_t hvB = seqB * hmul, hB = hash_slot(hvB), tgB = (hvB >> (32 - TAG_BITS - HASH_LOG)) & TAG_MASK;
             uint32_t eB = 0, tB = TAG_MASK + 1;
             if (actB) { eB = table[hB]; tB = tags[hB]; table[hB] = (uint16_t)pB; tags[hB] = (tag_t)tgB; }
             const uint32_t dB = (pB - eB) & 0xFFFFu;
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_
             const uint32_t q2 = ins2 ? ip - 2 : cs;
             const uint32_t v2 = ld32(base + q2);
             fill_queue();
-            if (ins2) { const uint32_t hv = v2 * hmul; table[hv >> (32 - HASH_LOG)] = (uint16_t)q2; tags[hv >> (32 - HASH_LOG)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
+            if (ins2) { const uint32_t hv = v2 * hmul; table[hash_slot(hv)] = (uint16_t)q2; tags[hash_slot(hv)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
             E1P(__builtin_amdgcn_sched_barrier(0); pt_restart += clock64() - pq3; __builtin_amdgcn_sched_barrier(0);)
         }
         E1P(if (prof && chunk == 1000 && lane == 0) { prof[64] = clock64() - pt_begin; prof[65] = pt_seeded - pt_begin; prof[66] = pt_probe; prof[67] = pt_verify; prof[68] = pt_ext; prof[69] = pt_restart; prof[70] = pn_iter; prof[71] = pn_ver; prof[72] = nrec; prof[73] = pt_begin - pt_kernel; })
