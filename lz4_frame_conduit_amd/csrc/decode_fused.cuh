@@ -36,7 +36,9 @@ constexpr uint32_t FZ_OVER = 576;                // >= the parser's 520-byte reg
 #ifndef FZ_FED_OCC
 #define FZ_FED_OCC 8
 #endif
-constexpr int      FZ_MATCH_SET = 3;            // match copies per register set (two sets in flight)
+constexpr int      FZ_MATCH_SET = 3;
+constexpr uint32_t FZ_SRC_BIAS = 1u << 22;       // direct matches: payload position relative to the block's payload + this (== IX_SRC_BIAS)
+constexpr uint32_t FZ_PREV_SPIN_MAX = 1u << 22; // polls of the previous block's "done" word before giving up (-> generic decoder)            // match copies per register set (two sets in flight)
 
 template <class C>
 struct alignas(16) FzShared {
@@ -235,8 +237,8 @@ __device__ __forceinline__ void fz_parser(FzShared<C>& sh, const uint8_t* __rest
 // the payload at the 23-bit position that then replaces the offset, so the copiers treat it like a literal run.
 template <class C>
 __device__ __forceinline__ void fz_feeder(FzShared<C>& sh, const SeqDesc* __restrict__ desc, const uint32_t* __restrict__ dsrc, uint32_t nseq,
-                                          uint32_t csize, uint32_t cap)
-{
+                                          uint32_t csize, uint32_t cap, uint64_t hist, uint64_t pay_before)
+{   // hist: output bytes in front of the block that a match may reach (linked frames); pay_before: frame bytes in front of the payload
     const uint32_t lane = lane_id();
     const uint32_t nslots = (nseq + 63) >> 6;
     uint32_t expect = 0, status = nseq ? 0u : 1u, published = 0;
@@ -262,11 +264,13 @@ __device__ __forceinline__ void fz_feeder(FzShared<C>& sh, const SeqDesc* __rest
         if (last) bad |= ml != 0 || direct;
         else {
             bad |= ml < 4 || end + 5 > cap;
-            bad |= direct ? ((uint64_t)f24 + ml > csize) : (f24 == 0 || f24 > 65535u || f24 > dm);
+            const int64_t rel = (int64_t)f24 - (int64_t)FZ_SRC_BIAS;             // direct: payload position relative to this block's payload
+            bad |= direct ? (rel + (int64_t)ml > (int64_t)csize || -rel > (int64_t)pay_before) : (f24 == 0 || f24 > 65535u || f24 > dm + hist);
         }
         if (__ballot(lane < count && bad)) { status = 1; break; }
         expect = __shfl((uint32_t)end, (int)count - 1);
-        while (slot >= lds_peek(&sh.match_done) + C::RING) __builtin_amdgcn_s_sleep(8);          // ring full: wait for the oldest slot
+        while (slot >= lds_peek(&sh.match_done) + C::RING && (int32_t)lds_peek((const uint32_t*)&sh.status) >= 0) __builtin_amdgcn_s_sleep(8);   // ring full: wait for the oldest slot
+        if ((int32_t)lds_peek((const uint32_t*)&sh.status) < 0) { status = 1; break; }          // (a copier gave up: previous block of a linked frame failed)
         sh.ring[slot % C::RING][lane] = d;
         if (slot + 1 == nslots) break;                                       // the last slot is published after the totals (see fz_parser)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -285,8 +289,9 @@ __device__ __forceinline__ void fz_feeder(FzShared<C>& sh, const SeqDesc* __rest
 // ---------------- copier waves ----------------
 template <class C, bool FED = false>
 __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __restrict__ in, uint8_t* out, uint32_t cw /* 0..6 */,
-                                          const uint8_t* safe /* 16 readable bytes */, unsigned long long* prof)
+                                          const uint8_t* safe /* 16 readable bytes */, unsigned long long* prof, const uint32_t* prev_done = nullptr)
 {
+    bool prev_ready = prev_done == nullptr;              // fed linked frames: the block in front is another workgroup's (see k_copy_indexed)
     const uint32_t lane = lane_id();
     unsigned long long t_wait_p = 0, t_lit = 0, t_wait_m = 0, t_match = 0, n_slots = 0, t_dep = 0, t_drain = 0;
     auto dump = [&]() { if (prof && blockIdx.x == 0 && lane == 0) { unsigned long long* o = prof + 8 * (cw + 1); o[0] = t_wait_p; o[1] = t_lit; o[2] = t_wait_m; o[3] = t_match; o[4] = n_slots; o[5] = t_dep; o[6] = t_drain; } };
@@ -310,7 +315,7 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
         const uint32_t vsrc = d.x & 0xFFFFFFu, vlen = d.y & 0xFFFFFFu, vdst = d.z, vml = FED ? (d.w & 0xFFFFFFu) : d.w, voff = (d.x >> 24) | ((d.y >> 24) << 8);
         // fed descriptors: a DIRECT match is one more copy out of the payload (position in the bits of the offset + 7 more)
         const bool vdirect = FED && lane < count && (d.w >> 31) != 0;
-        const uint32_t vmsrc = voff | (((d.w >> 24) & 0x7Fu) << 16);
+        const uint32_t vmsrc = (voff | (((d.w >> 24) & 0x7Fu) << 16)) - FZ_SRC_BIAS;       // signed: may point into the payload of the block before
 
         // ---- (1) literal runs (and direct matches): no dependencies.  A gather with no scalar work per run -- a CU has ONE
         // scalar unit, and a copy loop that spends ~100 scalar instructions per run is bound by it.  The runs of the slot are
@@ -357,7 +362,7 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
                     off = (off + 16u > len) ? len - 16u : off;
                     act = u < total;
                     dof = e1.z + (isM ? e0.z : 0u) + off;
-                    const uint8_t* a = act ? in + ((isM ? e1.y : e1.x) + off) : safe;
+                    const uint8_t* a = act ? in + (int32_t)((isM ? e1.y : e1.x) + off) : safe;
                     const v4u_ua t = *(const v4u_ua*)a;
                     pc.a = t.a; pc.b = t.b; pc.c = t.c; pc.d = t.d;
                 };
@@ -419,7 +424,7 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
                     r -= isM ? e0.y : 0u;
                     act[i] = u < total_b;
                     dof[i] = e1.z + (isM ? e0.z : 0u) + r;
-                    const uint8_t* a = act[i] ? in + ((isM ? e1.y : e1.x) + r) : safe;
+                    const uint8_t* a = act[i] ? in + (int32_t)((isM ? e1.y : e1.x) + r) : safe;
                     v[i] = *a;
                 }
 #pragma unroll
@@ -449,6 +454,19 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
             const int32_t ms0 = (int32_t)mdm - (int32_t)voff, ms1 = ms0 + (int32_t)vml;
             const bool has = lane < count && vml != 0 && !vdirect;             // direct matches went out with the literals
             const uint64_t fastmask = __ballot(has && vml >= 16 && vml <= 1024 && voff >= vml);   // one non-overlapping round
+            if (FED && !prev_ready && __ballot(has && ms0 < 0)) {
+                // a match of this slot reads what the workgroup of the block in front writes (linked frame): wait for its "done"
+                // word.  Workgroups are dispatched in block order, so that one is running or finished; the poll has a budget
+                // all the same, and a block that failed (2) or never answers sends the call to the generic decoder.
+                uint32_t v = 0;
+                for (uint32_t spin = 0; spin < FZ_PREV_SPIN_MAX; spin++) {
+                    v = __hip_atomic_load(prev_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (v != 1u) { lds_poke((uint32_t*)&sh.status, 0xFFFFFFFFu); dump(); return; }
+                prev_ready = true;
+            }
             uint32_t dep_lo = 0, dep_hi = 0;
             for (uint32_t k = 0; k < count && k < 32; k++) {
                 const uint32_t dk = __builtin_amdgcn_readlane(mdm, k), mk = __builtin_amdgcn_readlane(vml, k);
@@ -530,7 +548,7 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
 template <class C, bool FED = false>
 __device__ __forceinline__ int32_t fz_decode_block(FzShared<C>& sh, const uint8_t* __restrict__ in, uint32_t csize, uint8_t* out, uint32_t cap, uint64_t hist,
                                                    const uint8_t* safe, unsigned long long* prof, const SeqDesc* __restrict__ fed = nullptr, uint32_t nfed = 0,
-                                                   const uint32_t* __restrict__ fed_src = nullptr)
+                                                   const uint32_t* __restrict__ fed_src = nullptr, uint64_t pay_before = 0, const uint32_t* prev_done = nullptr)
 {
     const uint32_t wave = uni(threadIdx.x >> 6);
     __syncthreads();                                                     // previous block's LDS state is dead
@@ -538,11 +556,11 @@ __device__ __forceinline__ int32_t fz_decode_block(FzShared<C>& sh, const uint8_
     __syncthreads();
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);                                   // the serial chain: win issue arbitration against the 7 copier waves of this SIMD
-        if (FED) fz_feeder<C>(sh, fed, fed_src, nfed, csize, cap);
+        if (FED) fz_feeder<C>(sh, fed, fed_src, nfed, csize, cap, hist, pay_before);
         else fz_parser<C>(sh, in, csize, cap, hist, prof);
         __builtin_amdgcn_s_setprio(0);
     }
-    else fz_copier<C, FED>(sh, in, out, wave - 1, safe, prof);
+    else fz_copier<C, FED>(sh, in, out, wave - 1, safe, prof, prev_done);
     __syncthreads();                                                     // all copies of this block are issued and complete
     const int32_t st = (int32_t)uni((uint32_t)sh.status);
     const uint32_t osz = uni(sh.out_size);

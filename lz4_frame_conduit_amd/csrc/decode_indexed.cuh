@@ -68,7 +68,7 @@ __global__ void k_check_index(const void* __restrict__ ix, uint64_t ix_size, uin
 // a wrong index can make the call fall back, never change the bytes that come out.
 __device__ __forceinline__ void parse_entry(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
                                             const void* __restrict__ ix, uint32_t n_blocks, uint32_t n_entries,
-                                            SeqDesc* __restrict__ desc, uint64_t desc_cap, uint32_t* __restrict__ flags, uint32_t gid)
+                                            SeqDesc* __restrict__ desc, uint64_t desc_cap, uint32_t* __restrict__ flags, uint32_t gid, uint32_t linked)
 {
     const IxBlock* blocks = ix_blocks(ix);
     if (gid < n_blocks) {
@@ -154,16 +154,17 @@ __device__ __forceinline__ void parse_entry(const uint8_t* __restrict__ frame, u
         if (lit) remember(op, lit, p);
         if (mlen) {
             const uint32_t dm = op + lit;
-            if (off > dm) { bad = true; break; }
+            // a source in front of the block: only in a linked frame, and only as far as there is output before this block
+            if (off > dm && (!linked || (uint64_t)(off - dm) > e.dst_off)) { bad = true; break; }
             const uint32_t s0 = dm - off;
             uint32_t msrc = 0xFFFFFFFFu;
-            if (mlen <= off) {
+            if (mlen <= off && off <= dm) {
                 if (s0 >= r0o && s0 + mlen <= r0o + r0n) msrc = r0p + (s0 - r0o);
                 else if (s0 >= r1o && s0 + mlen <= r1o + r1n) msrc = r1p + (s0 - r1o);
                 else if (s0 >= r2o && s0 + mlen <= r2o + r2n) msrc = r2p + (s0 - r2o);
                 else if (s0 >= r3o && s0 + mlen <= r3o + r3n) msrc = r3p + (s0 - r3o);
             }
-            if (msrc < (1u << 23)) { f24 = msrc; mw |= 0x80000000u; remember(dm, mlen, msrc); }
+            if (msrc < IX_SRC_BIAS) { f24 = msrc + IX_SRC_BIAS; mw |= 0x80000000u; remember(dm, mlen, msrc); }
         }
         out[i] = SeqDesc{p | ((f24 & 0xFFu) << 24), lit | (((f24 >> 8) & 0xFFu) << 24), op, mw | (((f24 >> 16) & 0x7Fu) << 24)};
         op += lit + mlen;
@@ -174,14 +175,14 @@ __device__ __forceinline__ void parse_entry(const uint8_t* __restrict__ frame, u
 
 __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
                                                        const void* __restrict__ ix, uint32_t n_blocks,
-                                                       SeqDesc* __restrict__ desc, uint32_t* __restrict__ flags)
+                                                       SeqDesc* __restrict__ desc, uint32_t* __restrict__ flags, uint32_t linked)
 {
     if (*flags) return;
     const uint32_t n_entries = flags[8];
     const uint64_t desc_cap = flags[9];
     const uint32_t n_lanes = n_entries > n_blocks ? n_entries : n_blocks;
     for (uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n_lanes; gid += gridDim.x * blockDim.x)
-        parse_entry(frame, frame_cap, table, ix, n_blocks, n_entries, desc, desc_cap, flags, gid);
+        parse_entry(frame, frame_cap, table, ix, n_blocks, n_entries, desc, desc_cap, flags, gid, linked);
 }
 
 
@@ -192,47 +193,84 @@ __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict
 // a few hops at most.  Anything else (a source that straddles two runs, run-length matches) stays a match for the chain.
 // The descriptors are only read here; the answer goes to dsrc[i] (IX_NOT_DIRECT = none) and the feeder wave merges it in.
 constexpr uint32_t IXR_HOPS = 6;
+constexpr uint32_t IXL_CHAIN_FRACTION = 8;                     // linked frames: the indexed kernels take the frame if at most 1/8 of its sequences stay on the chain
 constexpr uint32_t IX_NOT_DIRECT = 0xFFFFFFFFu;
-__global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, const ResultRec* __restrict__ res, uint32_t n_max,
-                                                        const SeqDesc* __restrict__ desc, uint32_t* __restrict__ dsrc,
-                                                        uint32_t* __restrict__ flags, uint32_t count_it)
+// In a linked frame the source may start in the block before (offsets reach 64 KiB back): the search then runs over that
+// block's descriptors - or, if that block is stored, its payload IS its output.  The answer is the payload position
+// relative to the asking block's payload (negative for the block before) + IX_SRC_BIAS.
+__global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, const BlockOut* __restrict__ table, const ResultRec* __restrict__ res,
+                                                        uint32_t n_max, const SeqDesc* __restrict__ desc, uint32_t* __restrict__ dsrc,
+                                                        uint32_t* __restrict__ flags, uint32_t count_it, uint32_t linked)
 {
     if (res->status != ST_OK || *flags) return;
     const uint64_t desc_cap = flags[9];
-    const uint32_t b = blockIdx.y;
+    const uint32_t b = blockIdx.x;                             // (gridDim.y workgroups per block)
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
     if (b >= n) return;
-    const IxBlock blk = ix_blocks(ix)[b];
+    const IxBlock* blocks = ix_blocks(ix);
+    const IxBlock blk = blocks[b];
     if ((uint64_t)blk.seq_base + blk.nseq > desc_cap) return;
-    const SeqDesc* bd = desc + blk.seq_base;
-    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < blk.nseq; i += gridDim.x * 256) {        // gridDim.x workgroups per block
-        const SeqDesc d = bd[i];
+    const SeqDesc* bd0 = desc + blk.seq_base;
+    const uint64_t my_pay = table[b].src_off;
+    for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < blk.nseq; i += gridDim.y * 256) {
+        const SeqDesc d = bd0[i];
         const uint32_t ml = d.w & 0xFFFFFFu;
         uint32_t found = IX_NOT_DIRECT;
         if (ml != 0 && !(d.w >> 31)) {
             const uint32_t off = (d.x >> 24) | ((d.y >> 24) << 8), dm = d.z + (d.y & 0xFFFFFFu);
-            if (off <= dm && ml <= off) {                       // (overlapping matches replicate their own output: never direct)
-                uint32_t s0 = dm - off, hi = i;
+            if (ml <= off) {                                    // (overlapping matches replicate their own output: never direct)
+                int64_t s0 = (int64_t)dm - off;                 // source start, relative to the output of block cb
+                uint32_t cb = b, hi = i;
+                const SeqDesc* bd = bd0;
+                int64_t pay = 0;                                // payload of block cb relative to mine
                 for (uint32_t hop = 0; hop < IXR_HOPS; hop++) {
+                    if (s0 < 0) {                               // in the block before (linked frames)
+                        if (!linked || cb == 0) break;
+                        cb--;
+                        const BlockOut pe = table[cb];
+                        s0 += pe.dst_size;
+                        if (s0 < 0) break;                      // further back than one block: leave it to the chain
+                        pay = (int64_t)pe.src_off - (int64_t)my_pay;
+                        if (pe.word >> 31) {                    // stored: output position == payload position
+                            if ((uint64_t)s0 + ml <= pe.dst_size) { const int64_t v = pay + s0 + IX_SRC_BIAS; if (v >= 0 && v < (1 << 23)) found = (uint32_t)v; }
+                            break;
+                        }
+                        const IxBlock pb = blocks[cb];
+                        if (pb.nseq == 0 || (uint64_t)pb.seq_base + pb.nseq > desc_cap) break;
+                        bd = desc + pb.seq_base; hi = pb.nseq - 1;
+                    }
                     uint32_t lo = 0;                            // last sequence that starts at or before s0
+                    const uint32_t key = (uint32_t)s0;
                     while (lo < hi) {
                         const uint32_t mid = (lo + hi + 1) >> 1;
-                        if (bd[mid].z <= s0) lo = mid; else hi = mid - 1;
+                        if (bd[mid].z <= key) lo = mid; else hi = mid - 1;
                     }
                     const SeqDesc dj = bd[lo];
                     const uint32_t opj = dj.z, litj = dj.y & 0xFFFFFFu, mlj = dj.w & 0xFFFFFFu, dmj = opj + litj;
                     const uint32_t fj = (dj.x >> 24) | ((dj.y >> 24) << 8);
-                    if (s0 < opj) break;
-                    if ((uint64_t)s0 + ml <= dmj) { found = (dj.x & 0xFFFFFFu) + (s0 - opj); break; }             // in its literal run
-                    if (s0 < dmj || (uint64_t)s0 + ml > (uint64_t)dmj + mlj) break;                                // straddles
-                    if (dj.w >> 31) { found = (fj | (((dj.w >> 24) & 0x7Fu) << 16)) + (s0 - dmj); break; }         // in a direct match
-                    if (fj == 0 || fj > dmj || mlj > fj) break;                                                    // in a run-length match
-                    s0 -= fj; hi = lo;                                                                             // in a plain match: follow it
+                    if (key < opj) break;
+                    if ((uint64_t)key + ml <= dmj) {                                                               // in its literal run
+                        const int64_t v = pay + (dj.x & 0xFFFFFFu) + (key - opj) + IX_SRC_BIAS;
+                        if (v >= 0 && v < (1 << 23)) found = (uint32_t)v;
+                        break;
+                    }
+                    if (key < dmj || (uint64_t)key + ml > (uint64_t)dmj + mlj) break;                              // straddles
+                    if (dj.w >> 31) {                                                                              // in a direct match (marked by the parse)
+                        const int64_t v = pay + (int64_t)(fj | (((dj.w >> 24) & 0x7Fu) << 16)) + (key - dmj);      // (already biased)
+                        if (v >= 0 && v < (1 << 23)) found = (uint32_t)v;
+                        break;
+                    }
+                    if (fj == 0 || mlj > fj) break;                                                                // in a run-length match
+                    s0 -= fj; hi = lo;                                                                             // in a plain match: follow it (possibly into the block before)
                 }
-                if (found >= (1u << 23)) found = IX_NOT_DIRECT;
             }
             if (count_it) atomicAdd(flags + (found != IX_NOT_DIRECT ? 5 : 6), 1u);
+            if (count_it && linked && found == IX_NOT_DIRECT && off > dm) atomicAdd(flags + 11, 1u);
         } else if (count_it && ml) atomicAdd(flags + 4, 1u);
+        if (linked) {                                           // how long is the chain that stays? (one atomic per wave)
+            const uint64_t m = __ballot(ml != 0 && !(d.w >> 31) && found == IX_NOT_DIRECT);
+            if (m && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) atomicAdd(flags + 10, (uint32_t)__builtin_popcountll(m));
+        }
         dsrc[blk.seq_base + i] = found;
     }
 }
@@ -244,13 +282,17 @@ template <class C>
 __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(const uint8_t* __restrict__ frame, uint8_t* dst, BlockOut* __restrict__ table,
                                                                    const ResultRec* __restrict__ res, uint32_t n_max, void* __restrict__ ix,
                                                                    const SeqDesc* __restrict__ desc, const uint32_t* __restrict__ dsrc, uint32_t* __restrict__ flags,
-                                                                   unsigned long long* prof)
+                                                                   unsigned long long* prof, uint32_t linked, uint32_t* __restrict__ done)
 {
     __shared__ FzShared<C> sh;
     if (res->status != ST_OK || *flags) return;                              // index unusable: the generic kernel launched behind does the work
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
     const uint32_t b = blockIdx.x, tid = threadIdx.x;
     if (b >= n) return;
+    // Linked frame with most of its matches on the chain: the blocks then run one after the other (each waits for the block in
+    // front), and a workgroup per block polling its neighbour is the slowest way to walk one chain (measured: 30x slower
+    // than the window kernel on such data).  Leave those to decode_linked.cuh.
+    if (linked && (uint64_t)flags[10] * IXL_CHAIN_FRACTION > flags[9]) { if (b == 0 && tid == 0) atomicOr(flags, 4u); return; }
     const BlockOut e = table[b];
     const uint32_t csz = e.word & 0x7FFFFFFFu;
     int32_t got;
@@ -264,12 +306,19 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(cons
         }
     } else {
         const IxBlock blk = ix_blocks(ix)[b];
-        got = fz_decode_block<C, true>(sh, frame + e.src_off, csz, dst + e.dst_off, e.dst_size, 0, frame, prof, desc + blk.seq_base, blk.nseq,
-                                       dsrc ? dsrc + blk.seq_base : nullptr);
+        // linked frame: matches may reach into the output in front of the block (another workgroup's: `done`), direct matches
+        // into the payload in front of this one
+        const uint64_t hist = linked ? e.dst_off : 0ull;
+        got = fz_decode_block<C, true>(sh, frame + e.src_off, csz, dst + e.dst_off, e.dst_size, hist, frame, prof, desc + blk.seq_base, blk.nseq,
+                                       dsrc ? dsrc + blk.seq_base : nullptr, linked ? e.src_off : 0ull, (linked && b > 0) ? done + (b - 1) : nullptr);
     }
     // A block that did not come out (descriptors that do not tile the output, a bad offset, no room) is left as it was and
     // the generic kernel launched behind decodes the frame again: its verdict is the one the caller gets.
     if (tid == 0) { if (got < 0) atomicOr(flags, 2u); else table[b].dst_size = (uint32_t)got; }
+    if (linked) {                                                            // tell the block behind (its matches may read this output)
+        __syncthreads();
+        if (tid == 0) { __threadfence(); __hip_atomic_store(done + b, got < 0 ? 2u : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+    }
 }
 
 }  // namespace lz4f

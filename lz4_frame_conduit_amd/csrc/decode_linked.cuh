@@ -273,12 +273,12 @@ __device__ __forceinline__ void lk_literals(LkShared& sh, uint32_t me /* 0..LK_L
             // them work on the block the chain is at.  Pieces of <= 1 KiB go through two ping-pong register sets (two loads
             // each): four payload reads in flight per wave.  A piece goes to the output and - if it can still be a match
             // source - into the window; when the last piece of this wave's j-th run is stored, lit_prog[me] becomes j
-            struct LJob { const uint8_t* s; uint64_t d; uint32_t n, wi, fin; };   // n == 0 && fin == 0: none; fin: bit0 keep in window, bits 1.. = k+1 when last piece of run k
+            struct LJob { const uint8_t* s; uint64_t d; uint32_t n, wi, fin, rend; };   // n == 0 && fin == 0: none; fin: bit0 keep in window, bits 1.. = k+1 when last piece of run k; rend: where the run ends
             uint32_t k = me, at = 0;
             bool stop = false;
             auto next_job = [&]() -> LJob {
                 for (;;) {
-                    if (k >= count || stop) return LJob{safe, 0, 0, 0, 0};
+                    if (k >= count || stop) return LJob{safe, 0, 0, 0, 0, 0};
                     const uint32_t len = __builtin_amdgcn_readlane(vlen, k);
                     const uint64_t dabs = c.base + __builtin_amdgcn_readlane(vdst, k);
                     const uint8_t* sp = in + __builtin_amdgcn_readlane(vsrc, k);
@@ -286,14 +286,14 @@ __device__ __forceinline__ void lk_literals(LkShared& sh, uint32_t me /* 0..LK_L
                         if (dabs + len > dst_cap) { if (lane == 0) { sh.bad_block = c.block; sh.why = 5; sh.status = -2; } stop = true; continue; }
                         // the window may be written up to 64 KiB beyond the match the chain wave is at.  Not yet: hand out
                         // nothing, so that the runs already loaded get stored (the chain may be waiting for exactly those)
-                        if ((uint64_t)lds_peek(&sh.next_match_dst) + 65536 < dabs + len) return LJob{safe, 0, 0, 0, 0};
-                        if (len == 0) { k += LK_LITS; return LJob{safe, 0, 0, 0, (k / LK_LITS) << 1}; }   // nothing to copy, but the count must still advance in order
+                        if ((uint64_t)lds_peek(&sh.next_match_dst) + 65536 < dabs + len) return LJob{safe, 0, 0, 0, 0, 0};
+                        if (len == 0) { k += LK_LITS; return LJob{safe, 0, 0, 0, (k / LK_LITS) << 1, 0}; }   // nothing to copy, but the count must still advance in order
                     }
                     uint32_t nn = len - at; if (nn > 1024) nn = 1024;
                     const uint32_t wi = lk_widx((uint32_t)dabs + at);
                     if (nn > LK_WIN - wi) nn = LK_WIN - wi;                   // never across the end of the ring
                     const uint32_t keep = (len - at <= 65536 + 1024) ? 1u : 0u;   // only the last 64 KiB of a run can ever be a match source
-                    LJob j{sp + at, dabs + at, nn, wi, keep};
+                    LJob j{sp + at, dabs + at, nn, wi, keep, (uint32_t)(dabs + len)};
                     at += nn;
                     if (at >= len) { k += LK_LITS; j.fin |= (k / LK_LITS) << 1; at = 0; }
                     return j;
@@ -318,7 +318,23 @@ __device__ __forceinline__ void lk_literals(LkShared& sh, uint32_t me /* 0..LK_L
                     if (lane < nfull || (lane == nfull && tail)) {
                         const uint32_t o = lane < nfull ? lane * 16 : j.n - 16;
                         *(v4u_ua*)(out + j.d + o) = v4u_ua{pc.a, pc.b, pc.c, pc.d};
-                        if (j.fin & 1u) lk_win_write16(sh.win, j.wi + o, lk_v4{pc.a, pc.b, pc.c, pc.d});
+                        // Into the window only what can still be a match source: the last 64 KiB of the run, to the byte.  The
+                        // window is a ring of 128 KiB and the other literal waves may already be writing the 64 KiB beyond the
+                        // match the chain is at - for a run that ends there, anything older than 64 KiB would land on exactly
+                        // those positions (a stored 256 KiB block in front of a block that starts with literals, and the
+                        // newer bytes lost the race: found by tools/soak_indexed.py).
+                        if (j.fin & 1u) {
+                            const uint32_t age = j.rend - ((uint32_t)j.d + o);           // from my first byte to the end of the run
+                            if (age <= 65536u) lk_win_write16(sh.win, j.wi + o, lk_v4{pc.a, pc.b, pc.c, pc.d});
+                            else if (age < 65536u + 16u) {                               // straddles the line: the younger bytes, one by one
+                                const uint32_t first = age - 65536u;
+#pragma unroll
+                                for (uint32_t i = 1; i < 16; i++) {
+                                    const uint32_t w = i < 4 ? pc.a : i < 8 ? pc.b : i < 12 ? pc.c : pc.d;
+                                    if (i >= first) sh.win[j.wi + o + i] = (uint8_t)(w >> ((i & 3u) * 8u));
+                                }
+                            }
+                        }
                     }
                 } else if (lane < j.n) {
                     out[j.d + lane] = (uint8_t)pc.a;
@@ -326,7 +342,7 @@ __device__ __forceinline__ void lk_literals(LkShared& sh, uint32_t me /* 0..LK_L
                 }
                 if (j.fin >> 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lds_poke(&rg.lit_prog[idx][me], j.fin >> 1); }
             };
-            const LJob none{safe, 0, 0, 0, 0};
+            const LJob none{safe, 0, 0, 0, 0, 0};
             auto valid = [](const LJob& j) { return (j.n | j.fin) != 0; };
             for (uint32_t spin = 0; k < count && !stop;) {
                 // (a set's second job is only asked for when the first exists: the throttle may open between two calls, and
@@ -523,10 +539,13 @@ __device__ __forceinline__ void lk_chain(LkShared& sh, uint8_t* out, BlockOut* _
 
 __global__ __launch_bounds__(64 * LK_WAVES) void k_decode_linked(const uint8_t* __restrict__ frame, uint8_t* dst, uint64_t dst_cap,
                                                                  BlockOut* __restrict__ table, const ResultRec* __restrict__ res,
-                                                                 uint32_t n_max, uint32_t block_size, uint64_t hist0, uint32_t* __restrict__ fallback)
+                                                                 uint32_t n_max, uint32_t block_size, uint64_t hist0, uint32_t* __restrict__ fallback,
+                                                                 const uint32_t* __restrict__ only_if = nullptr)
 {   // fallback[0]: 1 = frame left to the generic kernel; fallback[1..2] (debug): which check stopped this kernel, at which block
+    // only_if: launched behind the indexed kernels (decode_indexed.cuh), runs only if they gave the frame up
     __shared__ LkShared sh;
     if (res->status != ST_OK) return;
+    if (only_if && *only_if == 0) { if (threadIdx.x == 0) *fallback = 0u; return; }
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
     const uint32_t tid = threadIdx.x, wave = uni(tid >> 6);
     if (tid == 0) { sh.next_match_dst = 0; sh.status = 0; sh.bad_block = LK_NONE; *fallback = 0u; sh.why = 0; }

@@ -566,6 +566,7 @@ __global__ __launch_bounds__(256) void k_layout_chunks(EncGeom g, ChunkInfo* __r
 //                                 exclusive scans over the blocks; the header
 //   pass E2                       writes the entries while it walks the records (it has both positions at hand)
 constexpr uint32_t IX_MAGIC = 0x3258494Cu;                     // "LIX2"
+constexpr uint32_t IX_SRC_BIAS = 1u << 22;                     // direct matches: payload position relative to the block's payload, + this (the source may sit in the block before)
 constexpr uint32_t IX_STRIDE = 16;                             // sequences per entry (a lane of the decoder walks one entry at memory latency)
 struct IxHeader { uint32_t magic, n_blocks, chunks_per_block, total_seqs, total_entries, stride, pad0, pad1; };
 struct IxBlock  { uint32_t seq_base, nseq, entry_base, nentries; };    // nseq == 0: stored block / nothing to index
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_index_blocks(EncGeom g, c
     if (b >= g.n_blocks || ix_capacity < ix_entries_at(g.n_blocks, g.chunks_per_block)) return;
     IxBlock* blocks = ix_blocks(ix);
     IxChunk* ck = ix_chunks(ix, g.n_blocks) + (uint64_t)b * g.chunks_per_block;
-    const bool usable = res->status == ST_OK && !g.linked;
+    const bool usable = res->status == ST_OK;              // (linked frames too: entries are per block, parsing needs no history)
     const BlockOut e = table[b];
     const ChunkInfo* ci = info + (uint64_t)b * g.chunks_per_block;
     const uint32_t nch = (e.dst_size + g.chunk_size - 1) / g.chunk_size;
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(1024) void k_build_index(EncGeom g, const ChunkInfo
     IxChunk* chunks = ix_chunks(ix, g.n_blocks);
     const size_t fixed = ix_entries_at(g.n_blocks, g.chunks_per_block);
     if (ix_capacity < fixed) { if (t == 0 && ix_capacity >= sizeof(IxHeader)) hd->magic = 0; return; }
-    const bool usable = res->status == ST_OK && !g.linked;
+    const bool usable = res->status == ST_OK;              // (linked frames too: entries are per block, parsing needs no history)
     // 1) per block: its chunks in order (unless k_index_blocks did that already)
     for (uint32_t b = t; b < g.n_blocks && !blocks_done; b += 1024) {
         const BlockOut e = table[b];
@@ -677,7 +678,7 @@ __global__ __launch_bounds__(1024) void k_build_index(EncGeom g, const ChunkInfo
     }
     if (t == 0) {
         const bool fits = (uint64_t)s_carry_b * sizeof(IxEntry) <= ix_capacity - fixed;     // else: too many sequences for this index, the decoder does without
-        *hd = IxHeader{usable && fits ? IX_MAGIC : 0u, g.n_blocks, g.chunks_per_block, s_carry_a, s_carry_b, IX_STRIDE, 0u, 0u};
+        *hd = IxHeader{usable && fits ? IX_MAGIC : 0u, g.n_blocks, g.chunks_per_block, s_carry_a, s_carry_b, IX_STRIDE, g.linked ? 1u : 0u, 0u};
     }
 }
 

@@ -272,7 +272,9 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         char mode = (j.linked || j.block_size >= (256u << 10)) ? 'f' : '1';
         if (const char* dv = getenv("LZ4F_MI355X_DECODE")) mode = dv[0];
         bool indexed = false;
-        if (mode == 'f' && j.d_index && j.index_size >= sizeof(IxHeader) && !j.linked && !getenv("LZ4F_MI355X_NO_INDEX")) {
+        // (linked frames: only with the compressor's table, which has every block's output position; one call decodes up to 4 GiB)
+        if (mode == 'f' && j.d_index && j.index_size >= sizeof(IxHeader) && (!j.linked || ((j.d_table || j.table_in_place) && j.hist0 == 0 && j.dst_cap < 0xFFF00000ull)) &&
+            !getenv("LZ4F_MI355X_NO_INDEX")) {
             // Descriptors from the compressor's sequence index: a lane per entry parses, a lane per sequence resolves direct
             // matches, a workgroup per block copies.  The descriptor workspace is sized from the index header.  The first
             // call reads it back (a host synchronisation); every call leaves a copy of its header in pinned memory behind the
@@ -296,33 +298,36 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             }
             if (ix_seq_cap) {
                 const size_t dsrc_at = (ix_seq_cap + 64) * sizeof(SeqDesc);
-                if (desc.ensure(dsrc_at + (ix_seq_cap + 64) * 4) || seqcnt.ensure(256)) return make_err(LZ4F_ERROR_allocation_failed);
-                HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 64, st));
+                if (desc.ensure(dsrc_at + (ix_seq_cap + 64) * 4) || seqcnt.ensure(256 + (size_t)n_max * 4)) return make_err(LZ4F_ERROR_allocation_failed);
+                HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 64 + (j.linked ? 192 + (size_t)n_max * 4 : 0), st));      // flags (+ the "done" word per block of a linked frame)
+                uint32_t* done = (uint32_t*)seqcnt.p + 64;
+                const uint32_t lk = j.linked ? 1u : 0u;
                 unsigned long long* iprof = (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr);
                 tick(8, false);
                 hipLaunchKernelGGL(k_check_index, dim3(1), dim3(64), 0, st, (const void*)j.d_index, (uint64_t)j.index_size, n_max, cpb, chunk,
                                    (uint64_t)ix_seq_cap, (uint32_t*)seqcnt.p);
                 uint32_t n_lanes = ix_entries_hint > n_max ? ix_entries_hint : n_max;           // (grid-stride inside: a hint is enough)
                 hipLaunchKernelGGL(k_parse_indexed, dim3((n_lanes + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap,
-                                   (const BlockOut*)tbl, (const void*)j.d_index, n_max, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p);
+                                   (const BlockOut*)tbl, (const void*)j.d_index, n_max, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, lk);
                 uint32_t* dsrc = (uint32_t*)((uint8_t*)desc.p + dsrc_at);
                 if (getenv("LZ4F_MI355X_NO_RESOLVE")) dsrc = nullptr;
                 else
-                    hipLaunchKernelGGL(k_resolve_direct, dim3(j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u, n_max), dim3(256), 0, st, j.d_index, (const ResultRec*)d_res, n_max, (const SeqDesc*)desc.p,
-                                       dsrc, (uint32_t*)seqcnt.p, iprof ? 1u : 0u);
+                    hipLaunchKernelGGL(k_resolve_direct, dim3(n_max, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u), dim3(256), 0, st, j.d_index, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, (const SeqDesc*)desc.p,
+                                       dsrc, (uint32_t*)seqcnt.p, iprof ? 1u : 0u, lk);
                 if (iprof) {                                                   // developer aid: how many matches are direct
                     uint32_t c[8];
                     if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(c, seqcnt.p, 32, hipMemcpyDeviceToHost) == hipSuccess)
                         fprintf(stderr, "indexed: flags %u, matches direct after parse %u, resolved %u, left to the chain %u\n", c[0], c[4], c[5], c[6]);
+                    uint32_t x[2] = {0, 0}; if (hipMemcpy(x, (uint32_t*)seqcnt.p + 10, 8, hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "indexed (linked): %u matches stay on the chain, %u of them reach into the block in front (%u blocks)\n", x[0], x[1], n_max);
                 }
                 tick(8, true);
                 tick(9, false);
                 if (j.block_size <= (1u << 20))
                     hipLaunchKernelGGL(k_copy_indexed<FzCfg<4>>, dim3(n_max), dim3(64 * 4), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_max,
-                                       j.d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof);
+                                       j.d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done);
                 else
                     hipLaunchKernelGGL(k_copy_indexed<FzCfg<8>>, dim3(n_max), dim3(64 * 8), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_max,
-                                       j.d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof);
+                                       j.d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done);
                 tick(9, true);
                 indexed = true;
             }
@@ -338,15 +343,16 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             // a linked frame is one chain: one workgroup with the 64 KiB window in LDS; frames with short (flushed) blocks
             // set the flag and are decoded by the generic kernel launched right behind (it returns at once otherwise)
             const bool windowed = j.linked && j.dst_cap < 0xFFF00000ull && !getenv("LZ4F_MI355X_NO_WINDOW");
-            const uint32_t* only_if = indexed ? (const uint32_t*)seqcnt.p : nullptr;      // behind the indexed kernels the generic one only runs if they gave up
+            const uint32_t* only_if = indexed ? (const uint32_t*)seqcnt.p : nullptr;      // behind the indexed kernels the generic ones only run if they gave up
             if (windowed) {
-                if (seqcnt.ensure(256)) return make_err(LZ4F_ERROR_allocation_failed);
+                if (!indexed && seqcnt.ensure(256)) return make_err(LZ4F_ERROR_allocation_failed);
+                uint32_t* fb = (uint32_t*)seqcnt.p + (indexed ? 16 : 0);                  // (word 0 is the indexed kernels' flag)
                 hipLaunchKernelGGL(k_decode_linked, dim3(1), dim3(64 * LK_WAVES), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
-                                   (const ResultRec*)d_res, n_max, j.block_size, j.hist0, (uint32_t*)seqcnt.p);
-                only_if = (const uint32_t*)seqcnt.p;
+                                   (const ResultRec*)d_res, n_max, j.block_size, j.hist0, fb, only_if);
+                only_if = fb;
                 if (getenv("LZ4F_MI355X_PROF")) {                              // developer aid: why the windowed kernel stopped, if it did
                     uint32_t dbg[3] = {0, 0, 0};
-                    if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(dbg, seqcnt.p, 12, hipMemcpyDeviceToHost) == hipSuccess)
+                    if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(dbg, fb, 12, hipMemcpyDeviceToHost) == hipSuccess)
                         fprintf(stderr, "k_decode_linked: fallback %u why %u block %u\n", dbg[0], dbg[1], dbg[2]);
                 }
             }

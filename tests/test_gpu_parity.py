@@ -542,8 +542,8 @@ def test_indexed_decode_same_bytes_as_generic(L):
     eng = Engine(0)
     used = 0
     for name, data in _indexed_inputs():
-        for bsid in (5, 6, 7):
-            kw = dict(bsid=bsid, indep=1, bck=1 if bsid == 6 else 0)
+        for bsid, indep in ((5, 1), (6, 1), (7, 1), (4, 0), (7, 0)):          # linked frames too (the reference's default framing is 64 KiB linked)
+            kw = dict(bsid=bsid, indep=indep, bck=1 if bsid == 6 else 0)
             src = torch.from_numpy(data).cuda()
             p = prefs_of(kw)
             bs = 1 << (8 + 2 * bsid)
@@ -566,7 +566,7 @@ def test_indexed_decode_same_bytes_as_generic(L):
             eng.decompress_blocks_async(frame, r.size, back, table, nb, p.frameInfo)
             r3 = eng.result()
             assert r3.size == src.numel() and torch.equal(back, src), (name, kw)
-    assert used >= 20                                                         # (dense streams may legitimately get an unusable index)
+    assert used >= 35                                                         # (dense streams may legitimately get an unusable index)
     eng.close()
 
 
@@ -620,7 +620,7 @@ def test_indexed_decode_survives_wrong_indexes(L):
     r = eng.result()
     assert int(small[:4].cpu().numpy().view(np.uint32)[0]) == 0
     check(src, frame, table, r.size, small)
-    # linked frames ignore the index
+    # linked frames: the same with their own index, a foreign one and a damaged one
     pl = prefs_of(dict(bsid=6, indep=0))
     frame_l = torch.empty(eng.frame_bound(src.numel(), pl), dtype=torch.uint8, device="cuda")
     idx = eng.new_index(src.numel(), pl)
@@ -629,4 +629,20 @@ def test_indexed_decode_survives_wrong_indexes(L):
     back = torch.zeros_like(src)
     eng.decompress_blocks_async(frame_l, r.size, back, table, nb, pl.frameInfo, idx)
     assert eng.result().size == src.numel() and torch.equal(back, src)
+    for other in (ib, torch.zeros_like(idx)):
+        back.zero_()
+        eng.decompress_blocks_async(frame_l, r.size, back, table, nb, pl.frameInfo, other)
+        assert eng.result().size == src.numel() and torch.equal(back, src)
+    sl = torch.from_numpy(b).cuda()                                            # synth50: this one takes the indexed kernels (block-parallel)
+    eng.compress_async(sl, frame_l, pl, table, idx)
+    r = eng.result()
+    for trial in range(8):
+        bad = idx.clone()
+        hdw = bad[:32].cpu().numpy().view(np.uint32)
+        words = bad[: 32 + nb * 16 + nb * int(hdw[2]) * 8 + int(hdw[4]) * 16].view(torch.int32)
+        at = int(rng.integers(8, words.numel()))
+        words[at] = int(words[at].item()) ^ (1 << int(rng.integers(0, 24)))
+        back = torch.zeros_like(sl)
+        eng.decompress_blocks_async(frame_l, r.size, back, table, nb, pl.frameInfo, bad)
+        assert eng.result().size == sl.numel() and torch.equal(back, sl)
     eng.close()

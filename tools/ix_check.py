@@ -10,7 +10,7 @@ bsid = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 kind = sys.argv[3] if len(sys.argv) > 3 else "synth50"
 n = mib << 20
 eng = Engine(0)
-p = conduit.make_preferences(blockSizeID=bsid, blockMode=1)
+p = conduit.make_preferences(blockSizeID=bsid, blockMode=0 if os.environ.get('LINKED') else 1)
 bs = 1 << (8 + 2 * bsid)
 def run(src, label):
     n = src.numel()
