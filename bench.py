@@ -128,7 +128,8 @@ def main():
     frame = torch.empty(eng.frame_bound(n, prefs), dtype=torch.uint8, device=dev)
     back = torch.empty_like(src)
     table = eng.new_table(nb)
-    index = None if (args.no_index or args.linked or bs < (256 << 10)) else eng.new_index(n, prefs)
+    # (the indexed kernels take independent blocks of 256 KiB and more, and linked frames of any block size)
+    index = None if (args.no_index or (not args.linked and bs < (256 << 10))) else eng.new_index(n, prefs)
     eng.set_timing(True)
 
     def step():

@@ -272,8 +272,8 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         char mode = (j.linked || j.block_size >= (256u << 10)) ? 'f' : '1';
         if (const char* dv = getenv("LZ4F_MI355X_DECODE")) mode = dv[0];
         bool indexed = false;
-        // (linked frames: only with the compressor's table, which has every block's output position; one call decodes up to 4 GiB)
-        if (mode == 'f' && j.d_index && j.index_size >= sizeof(IxHeader) && (!j.linked || ((j.d_table || j.table_in_place) && j.hist0 == 0 && j.dst_cap < 0xFFF00000ull)) &&
+        // (linked frames: only with the compressor's table, which has every block's output position)
+        if (mode == 'f' && j.d_index && j.index_size >= sizeof(IxHeader) && (!j.linked || ((j.d_table || j.table_in_place) && j.hist0 == 0)) &&
             !getenv("LZ4F_MI355X_NO_INDEX")) {
             // Descriptors from the compressor's sequence index: a lane per entry parses, a lane per sequence resolves direct
             // matches, a workgroup per block copies.  The descriptor workspace is sized from the index header.  The first
