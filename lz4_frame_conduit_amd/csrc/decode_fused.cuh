@@ -49,7 +49,8 @@ struct alignas(16) FzShared {
     uint32_t total_slots;                       // valid once `finished` is set
     uint32_t last_count;                        // descriptors in the last slot
     uint32_t finished;                          // parser is done (ok or not)
-    uint32_t match_done;                        // slots whose matches are complete (in slot order)
+    uint32_t match_done;                        // slots that are complete, in slot order (advanced over slot_done by whoever finishes)
+    uint32_t slot_done[C::RING];                // [slot % RING] == slot + 1: that slot's copies are all in memory
     int32_t  status;                            // < 0: malformed block
     uint32_t out_size;
     uint32_t pad;
@@ -434,13 +435,17 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
         // ---- (2) matches, in stream order, after every earlier slot's matches ----
         const unsigned long long c2 = clock64(); t_lit += c2 - c1;
         __builtin_amdgcn_s_setprio(0);
-        while (lds_peek(&sh.match_done) < slot) {
-            if ((int32_t)lds_peek((const uint32_t*)&sh.status) < 0) { dump(); return; }
-            __builtin_amdgcn_s_sleep(2);
+        // (a slot without a match on the chain - all direct, or literals only - neither waits for its predecessors nor is waited for)
+        const uint64_t on_chain = __ballot(lane < count && vml != 0 && !vdirect);
+        if (on_chain) {
+            while (lds_peek(&sh.match_done) < slot) {
+                if ((int32_t)lds_peek((const uint32_t*)&sh.status) < 0) { dump(); return; }
+                __builtin_amdgcn_s_sleep(2);
+            }
         }
         __builtin_amdgcn_sched_barrier(0); const unsigned long long c3 = clock64(); t_wait_m += c3 - c2; __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(2);                                       // the match phases form the second serial chain of a block
-        {
+        if (on_chain) {
             // Out-of-order replay.  A match may be copied as soon as every EARLIER match of this slot whose destination
             // overlaps its source has had its store issued (one wave's vector memory operations are performed in issue
             // order; earlier slots are complete, this slot's literals were written by this wave).  Later matches never
@@ -467,16 +472,15 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
                 if (v != 1u) { lds_poke((uint32_t*)&sh.status, 0xFFFFFFFFu); dump(); return; }
                 prev_ready = true;
             }
-            uint32_t dep_lo = 0, dep_hi = 0;
-            for (uint32_t k = 0; k < count && k < 32; k++) {
-                const uint32_t dk = __builtin_amdgcn_readlane(mdm, k), mk = __builtin_amdgcn_readlane(vml, k);
-                dep_lo |= (k < lane && mk != 0 && ms0 < (int32_t)(dk + mk) && ms1 > (int32_t)dk) ? (1u << k) : 0u;
-            }
-            for (uint32_t k = 32; k < count; k++) {
-                const uint32_t dk = __builtin_amdgcn_readlane(mdm, k), mk = __builtin_amdgcn_readlane(vml, k);
-                dep_hi |= (k < lane && mk != 0 && ms0 < (int32_t)(dk + mk) && ms1 > (int32_t)dk) ? (1u << (k - 32)) : 0u;
-            }
+            // (only over the matches that are on the chain: a slot whose matches are all direct costs a ballot here)
             uint64_t todo = __ballot(has), unstored = todo;
+            uint32_t dep_lo = 0, dep_hi = 0;
+            for (uint64_t mm = todo; mm; mm &= mm - 1) {
+                const uint32_t k = (uint32_t)__builtin_ctzll(mm);
+                const uint32_t dk = __builtin_amdgcn_readlane(mdm, k), mk = __builtin_amdgcn_readlane(vml, k);
+                const bool dep = k < lane && ms0 < (int32_t)(dk + mk) && ms1 > (int32_t)dk;
+                if (k < 32) dep_lo |= dep ? (1u << k) : 0u; else dep_hi |= dep ? (1u << (k - 32)) : 0u;
+            }
             __builtin_amdgcn_sched_barrier(0); t_dep += clock64() - c3; __builtin_amdgcn_sched_barrier(0);
             auto ready = [&]() -> uint64_t {
                 return __ballot(has && ((dep_lo & (uint32_t)unstored) | (dep_hi & (uint32_t)(unstored >> 32))) == 0) & todo;
@@ -538,7 +542,17 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
         __builtin_amdgcn_sched_barrier(0);
         t_drain += clock64() - c5;
         __builtin_amdgcn_sched_barrier(0);
-        lds_poke(&sh.match_done, slot + 1);
+        // this slot is done; `match_done` moves over every finished slot from the oldest unfinished one on.  Whoever finishes does
+        // that (flag first, then look: in LDS's one order of operations either I see the predecessor's bump or it sees my flag),
+        // so nobody waits for the order - a wave whose slot is not the oldest just leaves its flag and takes its next slot.
+        lds_poke(&sh.slot_done[slot % C::RING], slot + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (;;) {
+            const uint32_t md = lds_peek(&sh.match_done);
+            if (lds_peek(&sh.slot_done[md % C::RING]) != md + 1) break;
+            if (lane == 0) atomicCAS(&sh.match_done, md, md + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_setprio(0);
         t_match += clock64() - c3;
     }
@@ -553,6 +567,7 @@ __device__ __forceinline__ int32_t fz_decode_block(FzShared<C>& sh, const uint8_
     const uint32_t wave = uni(threadIdx.x >> 6);
     __syncthreads();                                                     // previous block's LDS state is dead
     if (threadIdx.x == 0) { sh.produced = 0; sh.total_slots = 0; sh.last_count = 64; sh.finished = 0; sh.match_done = 0; sh.status = 0; sh.out_size = 0; }
+    if (threadIdx.x < C::RING) sh.slot_done[threadIdx.x] = 0;
     __syncthreads();
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);                                   // the serial chain: win issue arbitration against the 7 copier waves of this SIMD
