@@ -78,10 +78,16 @@ def cpu_baseline(block_size: int, sample_bytes: int):
         except OSError:
             pass
     u = j["bytes"]
+    cpu = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
     e2e = u / (j["t_comp"] + j["t_decomp"]) / GIB
     return {"value": round(e2e, 3), "unit": "GiB/s", "cores": j["threads"], "kind": j["kind"],
             "sample": "%d MiB of synth50 (seed 1234), %d KiB independent blocks, block-parallel LZ4_compress_default + LZ4_decompress_safe, "
-                      "best of 3 after warm-up" % (u >> 20, block_size >> 10),
+                      "best of 3 after warm-up; host: %s" % (u >> 20, block_size >> 10, cpu),
             "compress_GiBs": round(u / j["t_comp"] / GIB, 3), "decompress_GiBs": round(u / j["t_decomp"] / GIB, 3),
             "ratio": round(u / j["compressed"], 4), "roundtrip_ok": j["roundtrip_ok"]}
 
