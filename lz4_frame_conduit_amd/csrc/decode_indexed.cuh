@@ -193,6 +193,7 @@ __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict
 // a few hops at most.  Anything else (a source that straddles two runs, run-length matches) stays a match for the chain.
 // The descriptors are only read here; the answer goes to dsrc[i] (IX_NOT_DIRECT = none) and the feeder wave merges it in.
 constexpr uint32_t IXR_HOPS = 6;
+constexpr uint32_t IXL_PUB = 8;                                // set-aside destinations a block publishes for the block behind (more: that one waits for all of it)
 constexpr uint32_t IXL_CHAIN_FRACTION = 8;                     // linked frames: the indexed kernels take the frame if at most 1/8 of its sequences stay on the chain
 constexpr uint32_t IX_NOT_DIRECT = 0xFFFFFFFFu;
 // In a linked frame the source may start in the block before (offsets reach 64 KiB back): the search then runs over that
@@ -314,10 +315,60 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(cons
     }
     // A block that did not come out (descriptors that do not tile the output, a bad offset, no room) is left as it was and
     // the generic kernel launched behind decodes the frame again: its verdict is the one the caller gets.
-    if (tid == 0) { if (got < 0) atomicOr(flags, 2u); else table[b].dst_size = (uint32_t)got; }
-    if (linked) {                                                            // tell the block behind (its matches may read this output)
+    if (!linked) { if (tid == 0) { if (got < 0) atomicOr(flags, 2u); else table[b].dst_size = (uint32_t)got; } return; }
+    // ---- linked frame: the matches this block set aside, and the word the block behind waits for ----
+    //   done[b]: 0 running, 3 main pass done (its set-aside destinations are published), 1 all done, 2 failed
+    // A set-aside match needs bytes of the block in front.  They are final once that block's main pass is over - unless they
+    // are among the bytes it set aside itself; only then does this block wait for all of it, so the blocks do not form a chain.
+    uint32_t* pcnt = done + n_max;
+    uint32_t* prange = done + 2 * (size_t)n_max + (size_t)b * 2 * IXL_PUB;
+    const uint32_t np = (got >= 0 && !(e.word >> 31)) ? uni(sh.pend_n) : 0u;
+    bool failed = got < 0;
+    if (np) {
+        if (np <= IXL_PUB && tid < np) { prange[2 * tid] = sh.pend_dst[tid]; prange[2 * tid + 1] = sh.pend_dst[tid] + sh.pend_len[tid]; }
         __syncthreads();
-        if (tid == 0) { __threadfence(); __hip_atomic_store(done + b, got < 0 ? 2u : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+        if (tid == 0) { pcnt[b] = np <= IXL_PUB ? np : 0xFFFFFFFFu; __threadfence(); __hip_atomic_store(done + b, 3u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+        if ((tid >> 6) == 0) {                                               // wave 0 replays
+            const uint32_t* pd = done + (b - 1);                             // (b > 0: a block without one in front sets nothing aside)
+            uint32_t v = 0;
+            auto poll = [&](bool all) {
+                for (uint32_t spin = 0; spin < FZ_PREV_SPIN_MAX; spin++) {
+                    v = __hip_atomic_load(pd, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v == 1u || v == 2u || (v == 3u && !all)) return;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                v = 2u;
+            };
+            poll(false);
+            if (v == 3u) {                                                   // do my sources touch what it still has to write?
+                const uint32_t pc = pcnt[b - 1];
+                bool hit = pc == 0xFFFFFFFFu;
+                if (!hit) {
+                    const int32_t psz = (int32_t)table[b - 1].dst_size;
+                    const uint32_t* pr = done + 2 * (size_t)n_max + (size_t)(b - 1) * 2 * IXL_PUB;
+                    for (uint32_t q = 0; q < np && !hit; q++) {
+                        const int32_t s0 = (int32_t)sh.pend_dst[q] - (int32_t)sh.pend_off[q];
+                        if (s0 >= 0) continue;
+                        const int32_t lo = psz + s0, hi = psz + ((s0 + (int32_t)sh.pend_len[q] < 0) ? s0 + (int32_t)sh.pend_len[q] : 0);
+                        for (uint32_t k = 0; k < pc; k++) hit |= lo < (int32_t)pr[2 * k + 1] && hi > (int32_t)pr[2 * k];
+                    }
+                }
+                if (hit) poll(true);
+            }
+            if (v == 2u) sh.status = -1;
+            else {
+                uint8_t* out = dst + e.dst_off;
+                for (uint32_t q = 0; q < np; q++) wave_copy_match(out + sh.pend_dst[q], sh.pend_off[q], sh.pend_len[q]);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __syncthreads();
+        failed = (int32_t)uni((uint32_t)sh.status) < 0;
+    }
+    if (tid == 0) {
+        if (failed) atomicOr(flags, 2u); else table[b].dst_size = (uint32_t)got;
+        __threadfence();
+        __hip_atomic_store(done + b, failed ? 2u : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -298,8 +298,8 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             }
             if (ix_seq_cap) {
                 const size_t dsrc_at = (ix_seq_cap + 64) * sizeof(SeqDesc);
-                if (desc.ensure(dsrc_at + (ix_seq_cap + 64) * 4) || seqcnt.ensure(256 + (size_t)n_max * 4)) return make_err(LZ4F_ERROR_allocation_failed);
-                HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 64 + (j.linked ? 192 + (size_t)n_max * 4 : 0), st));      // flags (+ the "done" word per block of a linked frame)
+                if (desc.ensure(dsrc_at + (ix_seq_cap + 64) * 4) || seqcnt.ensure(256 + (size_t)n_max * (8 + 8 * IXL_PUB))) return make_err(LZ4F_ERROR_allocation_failed);
+                HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 64 + (j.linked ? 192 + (size_t)n_max * 8 : 0), st));      // flags (+ per block of a linked frame: the "done" word and the count of published ranges)
                 uint32_t* done = (uint32_t*)seqcnt.p + 64;
                 const uint32_t lk = j.linked ? 1u : 0u;
                 unsigned long long* iprof = (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr);
