@@ -52,6 +52,7 @@ struct alignas(16) FzShared {
     uint32_t finished;                          // parser is done (ok or not)
     uint32_t match_done;                        // slots that are complete, in slot order (advanced over slot_done by whoever finishes)
     uint32_t slot_done[C::RING];                // [slot % RING] == slot + 1: that slot's copies are all in memory
+    uint32_t slot_cnt[C::RING];                 // fed descriptors: how many of them the slot holds (small blocks are cut into shorter slots)
     uint32_t pend_n, prev_ready;                // linked frames through the index: matches waiting for the block in front (see fz_copier)
     uint32_t pend_dst[FZ_PEND], pend_len[FZ_PEND], pend_off[FZ_PEND];
     int32_t  status;                            // < 0: malformed block
@@ -244,26 +245,31 @@ __device__ __forceinline__ void fz_feeder(FzShared<C>& sh, const SeqDesc* __rest
                                           uint32_t csize, uint32_t cap, uint64_t hist, uint64_t pay_before)
 {   // hist: output bytes in front of the block that a match may reach (linked frames); pay_before: frame bytes in front of the payload
     const uint32_t lane = lane_id();
-    const uint32_t nslots = (nseq + 63) >> 6;
+    // descriptors per slot: 64, fewer for a block so small that whole slots would leave copier waves without work
+    // (a 64 KiB block of 1 KiB sequences is ONE slot of 64: one busy wave per workgroup)
+    uint32_t per = (nseq + (C::WAVES - 1) - 1) / (C::WAVES - 1);
+    per = per > 64 ? 64u : (per < 8 ? 8u : per);
+    const uint32_t nslots = (nseq + per - 1) / per;
     uint32_t expect = 0, status = nseq ? 0u : 1u, published = 0;
     uint4 nxt = {0u, 0u, 0u, 0u};
     uint32_t nxt_src = 0xFFFFFFFFu;
-    if (lane < nseq) { nxt = ((const uint4*)desc)[lane]; if (dsrc) nxt_src = dsrc[lane]; }
+    if (lane < per && lane < nseq) { nxt = ((const uint4*)desc)[lane]; if (dsrc) nxt_src = dsrc[lane]; }
     for (uint32_t slot = 0; slot < nslots && !status; slot++) {
-        const uint32_t count = (nseq - slot * 64 < 64) ? nseq - slot * 64 : 64;
+        const uint32_t first = slot * per;
+        const uint32_t count = (nseq - first < per) ? nseq - first : per;
         uint4 d = nxt;
         if (nxt_src < (1u << 23) && !(d.w >> 31) && (d.w & 0xFFFFFFu))      // k_resolve_direct found the match's bytes in the payload
             d = uint4{(d.x & 0xFFFFFFu) | ((nxt_src & 0xFFu) << 24), (d.y & 0xFFFFFFu) | (((nxt_src >> 8) & 0xFFu) << 24), d.z,
                       (d.w & 0xFFFFFFu) | 0x80000000u | ((nxt_src >> 16) << 24)};
-        const uint32_t nx = (slot + 1) * 64 + lane;
+        const uint32_t nx = first + per + lane;
         nxt = uint4{0u, 0u, 0u, 0u}; nxt_src = 0xFFFFFFFFu;
-        if (nx < nseq) { nxt = ((const uint4*)desc)[nx]; if (dsrc) nxt_src = dsrc[nx]; }    // next slot's descriptors travel while this one is checked and published
+        if (lane < per && nx < nseq) { nxt = ((const uint4*)desc)[nx]; if (dsrc) nxt_src = dsrc[nx]; }    // next slot's descriptors travel while this one is checked and published
         const uint32_t p = d.x & 0xFFFFFFu, lit = d.y & 0xFFFFFFu, op = d.z, ml = d.w & 0xFFFFFFu;
         const bool direct = (d.w >> 31) != 0;
         const uint32_t f24 = (d.x >> 24) | ((d.y >> 24) << 8) | (((d.w >> 24) & 0x7Fu) << 16);
         const uint64_t dm = (uint64_t)op + lit, end = dm + ml;
         const uint32_t prev_end = __shfl_up((uint32_t)end, 1);
-        const bool last = slot * 64 + lane + 1 == nseq;
+        const bool last = first + lane + 1 == nseq;
         bool bad = op != (lane == 0 ? expect : prev_end) || (uint64_t)p + lit > csize || end > cap;
         if (last) bad |= ml != 0 || direct;
         else {
@@ -276,13 +282,14 @@ __device__ __forceinline__ void fz_feeder(FzShared<C>& sh, const SeqDesc* __rest
         while (slot >= lds_peek(&sh.match_done) + C::RING && (int32_t)lds_peek((const uint32_t*)&sh.status) >= 0) __builtin_amdgcn_s_sleep(8);   // ring full: wait for the oldest slot
         if ((int32_t)lds_peek((const uint32_t*)&sh.status) < 0) { status = 1; break; }          // (a copier gave up: previous block of a linked frame failed)
         sh.ring[slot % C::RING][lane] = d;
+        sh.slot_cnt[slot % C::RING] = count;
         if (slot + 1 == nslots) break;                                       // the last slot is published after the totals (see fz_parser)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         lds_poke(&sh.produced, slot + 1);
         published = slot + 1;
     }
     sh.total_slots = status ? published : nslots;
-    sh.last_count = status ? 64u : nseq - (nslots - 1) * 64;
+    sh.last_count = status ? 64u : nseq - (nslots - 1) * per;
     sh.out_size = expect;
     sh.status = status ? -1 : 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -313,7 +320,8 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
         const uint4 d = sh.ring[slot % C::RING][lane];
         // descriptors in this slot: 64, except a partial last slot -- which is published only after `finished`
         uint32_t count = 64;
-        if (lds_peek(&sh.finished) && slot + 1 == lds_peek(&sh.total_slots)) count = lds_peek(&sh.last_count);
+        if (FED) count = lds_peek(&sh.slot_cnt[slot % C::RING]);
+        else if (lds_peek(&sh.finished) && slot + 1 == lds_peek(&sh.total_slots)) count = lds_peek(&sh.last_count);
         count = uni(count);
         const uint32_t vsrc = d.x & 0xFFFFFFu, vlen = d.y & 0xFFFFFFu, vdst = d.z, vml = FED ? (d.w & 0xFFFFFFu) : d.w, voff = (d.x >> 24) | ((d.y >> 24) << 8);
         // fed descriptors: a DIRECT match is one more copy out of the payload (position in the bits of the offset + 7 more)
@@ -498,10 +506,11 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
                         // is running or finished; the poll has a budget), replay what is on the list, go on without one
                         uint32_t v = 0;                                       // (1 = all of it done, 2 = failed; 3 = only its main pass: not enough here)
                         for (uint32_t spin = 0; spin < FZ_PREV_SPIN_MAX; spin++) {
-                            v = __hip_atomic_load(prev_done, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                            v = __hip_atomic_load(prev_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             if (v == 1u || v == 2u) break;
                             __builtin_amdgcn_s_sleep(8);
                         }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                         if (v != 1u) { lds_poke((uint32_t*)&sh.status, 0xFFFFFFFFu); dump(); return; }
                         for (uint32_t q = 0; q < np; q++) wave_copy_match(out + sh.pend_dst[q], sh.pend_off[q], sh.pend_len[q]);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

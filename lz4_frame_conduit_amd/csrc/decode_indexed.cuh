@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, c
                         cb--;
                         const BlockOut pe = table[cb];
                         s0 += pe.dst_size;
-                        if (s0 < 0) break;                      // further back than one block: leave it to the chain
+                        if (s0 < 0) { if (count_it) atomicAdd(flags + 12, 1u); break; }                      // further back than one block: leave it to the chain
                         pay = (int64_t)pe.src_off - (int64_t)my_pay;
                         if (pe.word >> 31) {                    // stored: output position == payload position
                             if ((uint64_t)s0 + ml <= pe.dst_size) { const int64_t v = pay + s0 + IX_SRC_BIAS; if (v >= 0 && v < (1 << 23)) found = (uint32_t)v; }
@@ -255,13 +255,14 @@ __global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, c
                         if (v >= 0 && v < (1 << 23)) found = (uint32_t)v;
                         break;
                     }
-                    if (key < dmj || (uint64_t)key + ml > (uint64_t)dmj + mlj) break;                              // straddles
+                    if (key < dmj || (uint64_t)key + ml > (uint64_t)dmj + mlj) { if (count_it) atomicAdd(flags + 13, 1u); break; }                              // straddles
                     if (dj.w >> 31) {                                                                              // in a direct match (marked by the parse)
                         const int64_t v = pay + (int64_t)(fj | (((dj.w >> 24) & 0x7Fu) << 16)) + (key - dmj);      // (already biased)
                         if (v >= 0 && v < (1 << 23)) found = (uint32_t)v;
                         break;
                     }
-                    if (fj == 0 || mlj > fj) break;                                                                // in a run-length match
+                    if (fj == 0 || mlj > fj) { if (count_it) atomicAdd(flags + 14, 1u); break; }                                                                // in a run-length match
+                    if (count_it && hop + 1 == IXR_HOPS) atomicAdd(flags + 15, 1u);
                     s0 -= fj; hi = lo;                                                                             // in a plain match: follow it (possibly into the block before)
                 }
             }
@@ -332,14 +333,16 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(cons
             const uint32_t* pd = done + (b - 1);                             // (b > 0: a block without one in front sets nothing aside)
             uint32_t v = 0;
             auto poll = [&](bool all) {
+                // (relaxed polls, one acquire at the end: an acquire per poll would empty this CU's vector cache every time)
                 for (uint32_t spin = 0; spin < FZ_PREV_SPIN_MAX; spin++) {
-                    v = __hip_atomic_load(pd, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                    if (v == 1u || v == 2u || (v == 3u && !all)) return;
+                    v = __hip_atomic_load(pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v == 1u || v == 2u || (v == 3u && !all)) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); return; }
                     __builtin_amdgcn_s_sleep(8);
                 }
                 v = 2u;
             };
             poll(false);
+            if (prof && lane_id() == 0) { atomicAdd(flags + 22, 1u); if (v == 1u) atomicAdd(flags + 23, 1u); }
             if (v == 3u) {                                                   // do my sources touch what it still has to write?
                 const uint32_t pc = pcnt[b - 1];
                 bool hit = pc == 0xFFFFFFFFu;
@@ -353,6 +356,7 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(cons
                         for (uint32_t k = 0; k < pc; k++) hit |= lo < (int32_t)pr[2 * k + 1] && hi > (int32_t)pr[2 * k];
                     }
                 }
+                if (prof && lane_id() == 0) { atomicAdd(flags + 20, 1u); if (hit) atomicAdd(flags + 21, 1u); }
                 if (hit) poll(true);
             }
             if (v == 2u) sh.status = -1;

@@ -318,7 +318,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                     uint32_t c[8];
                     if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(c, seqcnt.p, 32, hipMemcpyDeviceToHost) == hipSuccess)
                         fprintf(stderr, "indexed: flags %u, matches direct after parse %u, resolved %u, left to the chain %u\n", c[0], c[4], c[5], c[6]);
-                    uint32_t x[2] = {0, 0}; if (hipMemcpy(x, (uint32_t*)seqcnt.p + 10, 8, hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "indexed (linked): %u matches stay on the chain, %u of them reach into the block in front (%u blocks)\n", x[0], x[1], n_max);
+                    uint32_t x[6] = {0, 0, 0, 0, 0, 0}; if (hipMemcpy(x, (uint32_t*)seqcnt.p + 10, 24, hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "indexed (linked): %u matches stay on the chain, %u of them reach into the block in front (%u blocks); not resolved because: beyond one block %u, source straddles two runs %u, run-length source %u, hop limit %u\n", x[0], x[1], n_max, x[2], x[3], x[4], x[5]);
                 }
                 tick(8, true);
                 tick(9, false);
@@ -329,6 +329,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                     hipLaunchKernelGGL(k_copy_indexed<FzCfg<8>>, dim3(n_max), dim3(64 * 8), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_max,
                                        j.d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done);
                 tick(9, true);
+                if (iprof && j.linked) { uint32_t y[4] = {0, 0, 0, 0}; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(y, (uint32_t*)seqcnt.p + 20, 16, hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "indexed (linked): blocks that found the block in front at state 3: %u (of those, had to wait for all of it: %u); blocks with set-aside matches %u (block in front already done: %u)\n", y[0], y[1], y[2], y[3]); }
                 indexed = true;
             }
             // this call's header for the next call (no wait here)
