@@ -371,6 +371,8 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(cons
     }
     if (tid == 0) {
         if (failed) atomicOr(flags, 2u); else table[b].dst_size = (uint32_t)got;
+        // (this release is what a small-block linked frame costs: the block behind may run on another XCD, so the fence writes
+        // this XCD's L2 back - measured ~65-130 ns per block at the level of the whole GPU, 5 of the 10 ms of 65536 blocks)
         __threadfence();
         __hip_atomic_store(done + b, failed ? 2u : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
