@@ -326,9 +326,13 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(cons
     const uint32_t np = (got >= 0 && !(e.word >> 31)) ? uni(sh.pend_n) : 0u;
     bool failed = got < 0;
     if (np) {
-        if (np <= IXL_PUB && tid < np) { prange[2 * tid] = sh.pend_dst[tid]; prange[2 * tid + 1] = sh.pend_dst[tid] + sh.pend_len[tid]; }
-        __syncthreads();
-        if (tid == 0) { pcnt[b] = np <= IXL_PUB ? np : 0xFFFFFFFFu; __threadfence(); __hip_atomic_store(done + b, 3u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+        // (state 3 is one more release fence: worth it for big blocks, where every block sets something aside and the replays would
+        // otherwise form a chain through the whole frame; small blocks just wait for all of the block in front)
+        if (e.dst_size >= (1u << 20)) {
+            if (np <= IXL_PUB && tid < np) { prange[2 * tid] = sh.pend_dst[tid]; prange[2 * tid + 1] = sh.pend_dst[tid] + sh.pend_len[tid]; }
+            __syncthreads();
+            if (tid == 0) { pcnt[b] = np <= IXL_PUB ? np : 0xFFFFFFFFu; __threadfence(); __hip_atomic_store(done + b, 3u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+        }
         if ((tid >> 6) == 0) {                                               // wave 0 replays
             const uint32_t* pd = done + (b - 1);                             // (b > 0: a block without one in front sets nothing aside)
             uint32_t v = 0;
