@@ -411,6 +411,42 @@ static void big_memcpy(void* dst, const void* src, size_t n)
     for (auto& x : th) x.join();
 }
 
+// Host buffer <-> device through the pinned staging buffer, in pieces: the copy between the caller's pageable memory and the
+// staging buffer (CPU threads) of one piece runs while the DMA of the piece before is in flight, instead of one after the other.
+static const size_t XFER_PIECE = (size_t)32 << 20;
+static hipError_t staged_h2d(void* d_dst, void* pinned, const void* src, size_t n, hipStream_t st)
+{
+    for (size_t a = 0; a < n; a += XFER_PIECE) {
+        const size_t len = std::min(XFER_PIECE, n - a);
+        big_memcpy((uint8_t*)pinned + a, (const uint8_t*)src + a, len);
+        hipError_t e = hipMemcpyAsync((uint8_t*)d_dst + a, (uint8_t*)pinned + a, len, hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+static hipError_t staged_d2h(void* dst, void* pinned, const void* d_src, size_t n, hipStream_t st)
+{
+    const size_t np = (n + XFER_PIECE - 1) / XFER_PIECE;
+    std::vector<hipEvent_t> ev(np);
+    hipError_t e = hipSuccess;
+    size_t made = 0;
+    for (size_t i = 0; i < np && e == hipSuccess; i++) {
+        const size_t a = i * XFER_PIECE, len = std::min(XFER_PIECE, n - a);
+        e = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming);
+        if (e != hipSuccess) break;
+        made++;
+        e = hipMemcpyAsync((uint8_t*)pinned + a, (const uint8_t*)d_src + a, len, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipEventRecord(ev[i], st);
+    }
+    for (size_t i = 0; i < made; i++) {
+        if (e == hipSuccess) e = hipEventSynchronize(ev[i]);
+        if (e == hipSuccess) { const size_t a = i * XFER_PIECE, len = std::min(XFER_PIECE, n - a); big_memcpy((uint8_t*)dst + a, (uint8_t*)pinned + a, len); }
+        (void)hipEventDestroy(ev[i]);
+    }
+    if (e != hipSuccess) (void)hipStreamSynchronize(st);
+    return e;
+}
+
 size_t lz4f_mi355x_engine::compress_blocks_host(const uint8_t* src, size_t n, const uint8_t* hist, size_t hist_len,
                                                 uint32_t block_size, bool linked, bool block_checksum, uint8_t* dst, size_t dst_cap, size_t* written)
 {
@@ -426,8 +462,8 @@ size_t lz4f_mi355x_engine::compress_blocks_host(const uint8_t* src, size_t n, co
     if (h_in.ensure(total) || d_in.ensure(total + 64) || d_out.ensure(out_cap) || h_out.ensure(out_cap + sizeof(ResultRec)) || res.ensure(sizeof(ResultRec)))
         return make_err(LZ4F_ERROR_allocation_failed);
     if (hist_len) memcpy(h_in.p, hist, hist_len);
-    big_memcpy((uint8_t*)h_in.p + hist_len, src, n);
-    HIP_TRY(hipMemcpyAsync(d_in.p, h_in.p, total, hipMemcpyHostToDevice, st));
+    if (hist_len) HIP_TRY(hipMemcpyAsync(d_in.p, h_in.p, hist_len, hipMemcpyHostToDevice, st));
+    HIP_TRY(staged_h2d((uint8_t*)d_in.p + hist_len, (uint8_t*)h_in.p + hist_len, src, n, st));
     CompressJob j; memset(&j, 0, sizeof(j));
     j.d_src = (const uint8_t*)d_in.p; j.src_size = total; j.first_off = hist_len; j.block_size = block_size;
     j.linked = linked; j.block_checksum = block_checksum; j.endmark = false; j.header_size = 0;
@@ -438,9 +474,7 @@ size_t lz4f_mi355x_engine::compress_blocks_host(const uint8_t* src, size_t n, co
     HIP_TRY(hipStreamSynchronize(st));
     if (hr->status != ST_OK) { set_last_error("device compress status %u", hr->status); return make_err((int)hr->status); }
     if (hr->size > dst_cap) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
-    HIP_TRY(hipMemcpyAsync(h_out.p, d_out.p, hr->size, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    big_memcpy(dst, h_out.p, hr->size);
+    HIP_TRY(staged_d2h(dst, h_out.p, d_out.p, hr->size, st));
     *written = hr->size;
     return 0;
 }
@@ -466,10 +500,9 @@ size_t lz4f_mi355x_engine::run_decode_slab(const uint8_t* frame_part, size_t par
         h_out.ensure(out_room + sizeof(ResultRec) + 64) || res.ensure(sizeof(ResultRec)) || table.ensure((nb + 1) * sizeof(BlockOut)))
         return make_err(LZ4F_ERROR_allocation_failed);
     uint8_t* hp = (uint8_t*)h_in.p;
-    big_memcpy(hp, frame_part, part_len);
     memcpy(hp + part_len, entries.data(), tbytes);
     if (hist_len) memcpy(hp + part_len + tbytes, hist, hist_len);
-    HIP_TRY(hipMemcpyAsync(d_in.p, hp, part_len, hipMemcpyHostToDevice, st));
+    HIP_TRY(staged_h2d(d_in.p, hp, frame_part, part_len, st));
     HIP_TRY(hipMemcpyAsync(table.p, hp + part_len, tbytes, hipMemcpyHostToDevice, st));
     if (hist_len) HIP_TRY(hipMemcpyAsync(d_out.p, hp + part_len + tbytes, hist_len, hipMemcpyHostToDevice, st));
     DecompressJob j; memset(&j, 0, sizeof(j));
@@ -483,9 +516,7 @@ size_t lz4f_mi355x_engine::run_decode_slab(const uint8_t* frame_part, size_t par
     HIP_TRY(hipStreamSynchronize(st));
     if (hr->status != ST_OK) { set_last_error("device decode status %u at block %u", hr->status, hr->first_bad_block); return status_to_err(hr->status); }
     if (hr->size > dst_room) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
-    HIP_TRY(hipMemcpyAsync(h_out.p, (uint8_t*)d_out.p + hist_len, hr->size, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    big_memcpy(dst, h_out.p, hr->size);
+    HIP_TRY(staged_d2h(dst, h_out.p, (uint8_t*)d_out.p + hist_len, hr->size, st));
     *got = hr->size;
     return 0;
 }
