@@ -646,3 +646,19 @@ def test_indexed_decode_survives_wrong_indexes(L):
         eng.decompress_blocks_async(frame_l, r.size, back, table, nb, pl.frameInfo, bad)
         assert eng.result().size == sl.numel() and torch.equal(back, sl)
     eng.close()
+
+
+def test_host_calls_across_staging_pieces(L):
+    """The host-pointer calls move data through pinned staging in 32 MiB pieces (copy and DMA overlapped): sizes around the
+    piece boundaries, a mixed stream, independent and linked frames; the oracle decodes what the GPU wrote."""
+    rng = np.random.default_rng(21)
+    for n in ((32 << 20) - 1, (32 << 20) + 1, (64 << 20) + 12345, (70 << 20) + 7):
+        data = np.concatenate([datagen.synth50(24 << 20, 3), rng.integers(0, 256, 9 << 20, dtype=np.uint8),
+                               np.frombuffer(datagen.structured(n - (33 << 20), 5), dtype=np.uint8)])[:n].tobytes()
+        for kw in (dict(bsid=7, indep=1, cck=1), dict(bsid=4, indep=0)):
+            frame = gpu_compress_frame(L, data, prefs_of(kw))
+            out, used = gpu_decompress_frame(L, frame, len(data) + 8)
+            assert used == len(frame) and out == data, (n, kw)
+            if n == (32 << 20) + 1:
+                ref, ref_used = oracle.decompress_frame(frame, cap=len(data) + 64)
+                assert ref_used == len(frame) and ref == data, (n, kw)
