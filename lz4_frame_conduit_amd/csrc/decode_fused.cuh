@@ -53,7 +53,8 @@ struct alignas(16) FzShared {
     uint32_t match_done;                        // slots that are complete, in slot order (advanced over slot_done by whoever finishes)
     uint32_t slot_done[C::RING];                // [slot % RING] == slot + 1: that slot's copies are all in memory
     uint32_t slot_cnt[C::RING];                 // fed descriptors: how many of them the slot holds (small blocks are cut into shorter slots)
-    uint32_t pend_n, prev_ready;                // linked frames through the index: matches waiting for the block in front (see fz_copier)
+    uint32_t pend_n, prev_ready, own_front;     // own_front: bytes of output in front of this block that are this workgroup's own (a group of linked blocks)
+    uint32_t pad_pend;   //               // linked frames through the index: matches waiting for the block in front (see fz_copier)
     uint32_t pend_dst[FZ_PEND], pend_len[FZ_PEND], pend_off[FZ_PEND];
     int32_t  status;                            // < 0: malformed block
     uint32_t out_size;
@@ -487,7 +488,7 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
                 // front is far enough (k_copy_indexed, after this block's main pass).  Everything else runs through; waiting here instead would stop the
                 // whole block after a ring's worth of slots (measured: 9.5 instead of ~3 ms for 4 GiB).
                 const uint32_t np = lds_peek(&sh.pend_n);
-                bool defer = has && ms0 < 0;
+                bool defer = has && ms0 < -(int32_t)lds_peek(&sh.own_front);      // reads another workgroup's output
                 for (uint32_t q = 0; q < np; q++) {
                     const int32_t lo = (int32_t)sh.pend_dst[q], hi = lo + (int32_t)sh.pend_len[q];
                     defer |= has && ms0 < hi && ms1 > lo;
@@ -512,7 +513,7 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                         if (v != 1u) { lds_poke((uint32_t*)&sh.status, 0xFFFFFFFFu); dump(); return; }
-                        for (uint32_t q = 0; q < np; q++) wave_copy_match(out + sh.pend_dst[q], sh.pend_off[q], sh.pend_len[q]);
+                        for (uint32_t q = 0; q < np; q++) wave_copy_match(out + (int32_t)sh.pend_dst[q], sh.pend_off[q], sh.pend_len[q]);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         lds_poke(&sh.pend_n, 0u);
                         lds_poke(&sh.prev_ready, 1u);
@@ -607,13 +608,15 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
 template <class C, bool FED = false>
 __device__ __forceinline__ int32_t fz_decode_block(FzShared<C>& sh, const uint8_t* __restrict__ in, uint32_t csize, uint8_t* out, uint32_t cap, uint64_t hist,
                                                    const uint8_t* safe, unsigned long long* prof, const SeqDesc* __restrict__ fed = nullptr, uint32_t nfed = 0,
-                                                   const uint32_t* __restrict__ fed_src = nullptr, uint64_t pay_before = 0, const uint32_t* prev_done = nullptr)
-{
+                                                   const uint32_t* __restrict__ fed_src = nullptr, uint64_t pay_before = 0, const uint32_t* prev_done = nullptr,
+                                                   uint32_t own_front = 0, bool first_of_group = true)
+{   // first_of_group == false: a later block of a group of linked blocks this workgroup decodes one after the other - the list of
+    // set-aside matches is carried over (positions rebased by the caller), and sources in front of the block are this workgroup's own
     const uint32_t wave = uni(threadIdx.x >> 6);
     __syncthreads();                                                     // previous block's LDS state is dead
     if (threadIdx.x == 0) { sh.produced = 0; sh.total_slots = 0; sh.last_count = 64; sh.finished = 0; sh.match_done = 0; sh.status = 0; sh.out_size = 0; }
     if (threadIdx.x < C::RING) sh.slot_done[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { sh.pend_n = 0; sh.prev_ready = 0; }
+    if (threadIdx.x == 0) { if (first_of_group) { sh.pend_n = 0; sh.prev_ready = 0; } sh.own_front = own_front; }
     __syncthreads();
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);                                   // the serial chain: win issue arbitration against the 7 copier waves of this SIMD

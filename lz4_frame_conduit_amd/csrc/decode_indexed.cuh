@@ -284,57 +284,96 @@ template <class C>
 __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(const uint8_t* __restrict__ frame, uint8_t* dst, BlockOut* __restrict__ table,
                                                                    const ResultRec* __restrict__ res, uint32_t n_max, void* __restrict__ ix,
                                                                    const SeqDesc* __restrict__ desc, const uint32_t* __restrict__ dsrc, uint32_t* __restrict__ flags,
-                                                                   unsigned long long* prof, uint32_t linked, uint32_t* __restrict__ done)
-{
+                                                                   unsigned long long* prof, uint32_t linked, uint32_t* __restrict__ done, uint32_t group)
+{   // group: consecutive blocks per workgroup (1 except for small blocks of a linked frame, see below)
     __shared__ FzShared<C> sh;
     if (res->status != ST_OK || *flags) return;                              // index unusable: the generic kernel launched behind does the work
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
-    const uint32_t b = blockIdx.x, tid = threadIdx.x;
-    if (b >= n) return;
+    const uint32_t g = blockIdx.x, tid = threadIdx.x;
+    const uint32_t b0 = g * group;
+    if (b0 >= n) return;
+    const uint32_t b1 = (b0 + group < n) ? b0 + group : n;
     // Linked frame with most of its matches on the chain: the blocks then run one after the other (each waits for the block in
     // front), and a workgroup per block polling its neighbour is the slowest way to walk one chain (measured: 30x slower
     // than the window kernel on such data).  Leave those to decode_linked.cuh.
-    if (linked && (uint64_t)flags[10] * IXL_CHAIN_FRACTION > flags[9]) { if (b == 0 && tid == 0) atomicOr(flags, 4u); return; }
-    const BlockOut e = table[b];
-    const uint32_t csz = e.word & 0x7FFFFFFFu;
-    int32_t got;
-    if (e.word >> 31) {                                                      // stored block: all waves copy a slice
-        got = -2;
-        if (csz <= e.dst_size) {
-            const uint32_t per = (((csz + C::WAVES - 1) / C::WAVES) + 15) & ~15u;
-            const uint32_t a = (tid >> 6) * per;
-            if (a < csz) wave_copy_disjoint(dst + e.dst_off + a, frame + e.src_off + a, (csz - a < per) ? csz - a : per);
-            got = (int32_t)csz;
+    if (linked && (uint64_t)flags[10] * IXL_CHAIN_FRACTION > flags[9]) { if (g == 0 && tid == 0) atomicOr(flags, 4u); return; }
+    if (!linked) {                                                           // (group == 1)
+        const uint32_t b = b0;
+        const BlockOut e = table[b];
+        const uint32_t csz = e.word & 0x7FFFFFFFu;
+        int32_t got;
+        if (e.word >> 31) {                                                  // stored block: all waves copy a slice
+            got = -2;
+            if (csz <= e.dst_size) {
+                const uint32_t per = (((csz + C::WAVES - 1) / C::WAVES) + 15) & ~15u;
+                const uint32_t a = (tid >> 6) * per;
+                if (a < csz) wave_copy_disjoint(dst + e.dst_off + a, frame + e.src_off + a, (csz - a < per) ? csz - a : per);
+                got = (int32_t)csz;
+            }
+        } else {
+            const IxBlock blk = ix_blocks(ix)[b];
+            got = fz_decode_block<C, true>(sh, frame + e.src_off, csz, dst + e.dst_off, e.dst_size, 0, frame, prof, desc + blk.seq_base, blk.nseq,
+                                           dsrc ? dsrc + blk.seq_base : nullptr, 0ull, nullptr, 0u, true);
         }
-    } else {
-        const IxBlock blk = ix_blocks(ix)[b];
-        // linked frame: matches may reach into the output in front of the block (another workgroup's: `done`), direct matches
-        // into the payload in front of this one
-        const uint64_t hist = linked ? e.dst_off : 0ull;
-        got = fz_decode_block<C, true>(sh, frame + e.src_off, csz, dst + e.dst_off, e.dst_size, hist, frame, prof, desc + blk.seq_base, blk.nseq,
-                                       dsrc ? dsrc + blk.seq_base : nullptr, linked ? e.src_off : 0ull, (linked && b > 0) ? done + (b - 1) : nullptr);
+        // A block that did not come out (descriptors that do not tile the output, a bad offset, no room) is left as it was and
+        // the generic kernel launched behind decodes the frame again: its verdict is the one the caller gets.
+        if (tid == 0) { if (got < 0) atomicOr(flags, 2u); else table[b].dst_size = (uint32_t)got; }
+        return;
     }
-    // A block that did not come out (descriptors that do not tile the output, a bad offset, no room) is left as it was and
-    // the generic kernel launched behind decodes the frame again: its verdict is the one the caller gets.
-    if (!linked) { if (tid == 0) { if (got < 0) atomicOr(flags, 2u); else table[b].dst_size = (uint32_t)got; } return; }
-    // ---- linked frame: the matches this block set aside, and the word the block behind waits for ----
-    //   done[b]: 0 running, 3 main pass done (its set-aside destinations are published), 1 all done, 2 failed
-    // A set-aside match needs bytes of the block in front.  They are final once that block's main pass is over - unless they
-    // are among the bytes it set aside itself; only then does this block wait for all of it, so the blocks do not form a chain.
+    // ---- linked frame ----
+    // A workgroup decodes `group` consecutive blocks one after the other; matches may reach into the output in front of a block,
+    // direct matches into the payload in front of it.  In front of the group's first block that output is another workgroup's:
+    // matches that read it (and whatever reads what they will write) are SET ASIDE (fz_copier) - the list lives through the whole
+    // group, rebased from block to block - and replayed at the end, when the group in front says so:
+    //   done[g]: 0 running, 3 main pass done (its set-aside destinations are published; group == 1 only), 1 all done, 2 failed
+    // A set-aside match needs bytes of the group in front.  They are final once that one's main pass is over - unless they are among
+    // the bytes it set aside itself; only then does this one wait for all of it, so big blocks do not form a chain.  Why groups:
+    // every word left for the neighbour needs an agent-scope release, and with the neighbour possibly on another XCD that fence
+    // writes this XCD's L2 back (~65-130 ns each at the level of the whole GPU: 65536 single blocks of 64 KiB cost 7 ms of them).
+    bool failed = false;
+    uint32_t last_size = 0, own_front = 0;
+    BlockOut e{};
+    for (uint32_t b = b0; b < b1 && !failed; b++) {
+        e = table[b];
+        const uint32_t csz = e.word & 0x7FFFFFFFu;
+        if (b > b0) {                                                        // the list of set-aside matches moves on with the block base
+            __syncthreads();
+            if (tid < FZ_PEND && tid < sh.pend_n) sh.pend_dst[tid] -= last_size;
+            __syncthreads();
+        }
+        int32_t got;
+        if (e.word >> 31) {
+            got = -2;
+            if (csz <= e.dst_size) {
+                const uint32_t per = (((csz + C::WAVES - 1) / C::WAVES) + 15) & ~15u;
+                const uint32_t a = (tid >> 6) * per;
+                if (a < csz) wave_copy_disjoint(dst + e.dst_off + a, frame + e.src_off + a, (csz - a < per) ? csz - a : per);
+                got = (int32_t)csz;
+                if (b == b0) { __syncthreads(); if (tid == 0) { sh.pend_n = 0; sh.prev_ready = 0; sh.status = 0; } __syncthreads(); }   // (a stored block sets nothing aside)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        } else {
+            const IxBlock blk = ix_blocks(ix)[b];
+            got = fz_decode_block<C, true>(sh, frame + e.src_off, csz, dst + e.dst_off, e.dst_size, e.dst_off, frame, prof, desc + blk.seq_base, blk.nseq,
+                                           dsrc ? dsrc + blk.seq_base : nullptr, e.src_off, g > 0 ? done + (g - 1) : nullptr, own_front, b == b0);
+        }
+        if (got < 0) failed = true;
+        else { if (tid == 0) table[b].dst_size = (uint32_t)got; last_size = (uint32_t)got; own_front = own_front + last_size < (1u << 30) ? own_front + last_size : (1u << 30); }
+    }
+    __syncthreads();
+    const uint32_t np = failed ? 0u : uni(sh.pend_n);
     uint32_t* pcnt = done + n_max;
-    uint32_t* prange = done + 2 * (size_t)n_max + (size_t)b * 2 * IXL_PUB;
-    const uint32_t np = (got >= 0 && !(e.word >> 31)) ? uni(sh.pend_n) : 0u;
-    bool failed = got < 0;
+    uint32_t* prange = done + 2 * (size_t)n_max + (size_t)g * 2 * IXL_PUB;
     if (np) {
         // (state 3 is one more release fence: worth it for big blocks, where every block sets something aside and the replays would
-        // otherwise form a chain through the whole frame; small blocks just wait for all of the block in front)
-        if (e.dst_size >= (1u << 20)) {
+        // otherwise form a chain through the whole frame; groups of small blocks just wait for all of the group in front)
+        if (group == 1 && e.dst_size >= (1u << 20)) {
             if (np <= IXL_PUB && tid < np) { prange[2 * tid] = sh.pend_dst[tid]; prange[2 * tid + 1] = sh.pend_dst[tid] + sh.pend_len[tid]; }
             __syncthreads();
-            if (tid == 0) { pcnt[b] = np <= IXL_PUB ? np : 0xFFFFFFFFu; __threadfence(); __hip_atomic_store(done + b, 3u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+            if (tid == 0) { pcnt[g] = np <= IXL_PUB ? np : 0xFFFFFFFFu; __threadfence(); __hip_atomic_store(done + g, 3u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
         }
         if ((tid >> 6) == 0) {                                               // wave 0 replays
-            const uint32_t* pd = done + (b - 1);                             // (b > 0: a block without one in front sets nothing aside)
+            const uint32_t* pd = done + (g - 1);                             // (g > 0: a group without one in front sets nothing aside)
             uint32_t v = 0;
             auto poll = [&](bool all) {
                 // (relaxed polls, one acquire at the end: an acquire per poll would empty this CU's vector cache every time)
@@ -347,12 +386,12 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(cons
             };
             poll(false);
             if (prof && lane_id() == 0) { atomicAdd(flags + 22, 1u); if (v == 1u) atomicAdd(flags + 23, 1u); }
-            if (v == 3u) {                                                   // do my sources touch what it still has to write?
-                const uint32_t pc = pcnt[b - 1];
+            if (v == 3u) {                                                   // (group == 1) do my sources touch what it still has to write?
+                const uint32_t pc = pcnt[g - 1];
                 bool hit = pc == 0xFFFFFFFFu;
                 if (!hit) {
-                    const int32_t psz = (int32_t)table[b - 1].dst_size;
-                    const uint32_t* pr = done + 2 * (size_t)n_max + (size_t)(b - 1) * 2 * IXL_PUB;
+                    const int32_t psz = (int32_t)table[b0 - 1].dst_size;
+                    const uint32_t* pr = done + 2 * (size_t)n_max + (size_t)(g - 1) * 2 * IXL_PUB;
                     for (uint32_t q = 0; q < np && !hit; q++) {
                         const int32_t s0 = (int32_t)sh.pend_dst[q] - (int32_t)sh.pend_off[q];
                         if (s0 >= 0) continue;
@@ -365,20 +404,19 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(cons
             }
             if (v == 2u) sh.status = -1;
             else {
-                uint8_t* out = dst + e.dst_off;
-                for (uint32_t q = 0; q < np; q++) wave_copy_match(out + sh.pend_dst[q], sh.pend_off[q], sh.pend_len[q]);
+                uint8_t* out = dst + e.dst_off;                              // (positions on the list are relative to the group's last block)
+                for (uint32_t q = 0; q < np; q++) wave_copy_match(out + (int32_t)sh.pend_dst[q], sh.pend_off[q], sh.pend_len[q]);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
         }
         __syncthreads();
-        failed = (int32_t)uni((uint32_t)sh.status) < 0;
+        failed = failed || (int32_t)uni((uint32_t)sh.status) < 0;
     }
     if (tid == 0) {
-        if (failed) atomicOr(flags, 2u); else table[b].dst_size = (uint32_t)got;
-        // (this release is what a small-block linked frame costs: the block behind may run on another XCD, so the fence writes
-        // this XCD's L2 back - measured ~65-130 ns per block at the level of the whole GPU, 5 of the 10 ms of 65536 blocks)
+        if (failed) atomicOr(flags, 2u);
+        // (this release is what a linked frame of small blocks costs, hence the groups)
         __threadfence();
-        __hip_atomic_store(done + b, failed ? 2u : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done + g, failed ? 2u : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
