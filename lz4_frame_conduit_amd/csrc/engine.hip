@@ -117,7 +117,7 @@ lz4f_mi355x_engine::~lz4f_mi355x_engine()
 {
     (void)hipSetDevice(device);
     (void)hipStreamSynchronize((hipStream_t)stream);
-    desc.release(); seqcnt.release();
+    desc.release(); seqcnt.release(); selfix.release(); selfcnt.release();
     info.release(); recs.release(); table.release(); blk_bytes.release(); res.release(); bad.release();
     d_in.release(); d_out.release();
     h_in.release(); h_out.release(); h_small.release();
@@ -272,8 +272,44 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         char mode = (j.linked || j.block_size >= (256u << 10)) ? 'f' : '1';
         if (const char* dv = getenv("LZ4F_MI355X_DECODE")) mode = dv[0];
         bool indexed = false;
-        // (linked frames: only with the compressor's table, which has every block's output position)
-        if (mode == 'f' && j.d_index && j.index_size >= sizeof(IxHeader) && (!j.linked || ((j.d_table || j.table_in_place) && j.hist0 == 0)) &&
+        void* d_index = j.d_index; size_t index_size = j.index_size;
+        bool self_indexed = false;
+        if (mode == 'f' && j.linked && !j.d_index && j.hist0 == 0 && n_max >= 2 && !getenv("LZ4F_MI355X_NO_INDEX") && !getenv("LZ4F_MI355X_NO_SELFINDEX")) {
+            // A linked frame without an index (a foreign one: the reference's default output): make the index here - a lane per block
+            // walks the payload (parsing needs no history), a scan places the blocks - and take the same kernels as with the
+            // compressor's index.  Two host synchronisations (the totals size the buffers); anything odd leaves the frame to the
+            // window kernel, as before.
+            const uint32_t cpb = j.block_size / pick_chunk_size(j.block_size);
+            const size_t fixed = ix_entries_at(n_max, cpb);
+            if (selfcnt.ensure((size_t)n_max * 8 + 64) || seqcnt.ensure(256 + (size_t)n_max * (8 + 8 * IXL_PUB)) || selfix.ensure(fixed + 64))
+                return make_err(LZ4F_ERROR_allocation_failed);
+            uint32_t* cnt = (uint32_t*)selfcnt.p; uint32_t* osz = cnt + n_max;
+            HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 64, st));
+            hipLaunchKernelGGL(k_selfindex_walk<0>, dim3((n_max + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl,
+                               (const ResultRec*)d_res, n_max, cnt, osz, (void*)nullptr, (uint32_t*)seqcnt.p);
+            uint32_t tot[10];
+            for (int pass = 0; pass < 2; pass++) {
+                hipLaunchKernelGGL(k_selfindex_scan, dim3(1), dim3(1024), 0, st, tbl, (const ResultRec*)d_res, n_max, (const uint32_t*)cnt, (const uint32_t*)osz,
+                                   selfix.p, cpb, (uint64_t)j.dst_cap, j.block_size, (uint32_t*)seqcnt.p);
+                if (pass == 1) break;
+                HIP_TRY(hipMemcpyAsync(tot, seqcnt.p, sizeof(tot), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (tot[0] != 0 || tot[9] == 0) break;
+                const void* before = selfix.p;
+                if (selfix.ensure(fixed + (size_t)tot[8] * sizeof(IxEntry) + 64)) return make_err(LZ4F_ERROR_allocation_failed);
+                if (selfix.p == before) break;                                   // (same buffer: the block table is already in it)
+            }
+            if (tot[0] == 0 && tot[9] != 0) {
+                hipLaunchKernelGGL(k_selfindex_walk<1>, dim3((n_max + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl,
+                                   (const ResultRec*)d_res, n_max, cnt, osz, selfix.p, (uint32_t*)seqcnt.p);
+                d_index = selfix.p; index_size = fixed + (size_t)tot[8] * sizeof(IxEntry);
+                self_indexed = true;
+                if (ix_seq_cap < (size_t)tot[9] + 4096) ix_seq_cap = (size_t)tot[9] + 4096;
+                if (ix_entries_hint < tot[8]) ix_entries_hint = tot[8];
+            }
+        }
+        // (linked frames: only with a table that has every block's output position - the compressor's, or the one just made)
+        if (mode == 'f' && d_index && index_size >= sizeof(IxHeader) && (!j.linked || self_indexed || ((j.d_table || j.table_in_place) && j.hist0 == 0)) &&
             !getenv("LZ4F_MI355X_NO_INDEX")) {
             // Descriptors from the compressor's sequence index: a lane per entry parses, a lane per sequence resolves direct
             // matches, a workgroup per block copies.  The descriptor workspace is sized from the index header.  The first
@@ -287,12 +323,12 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             bool have = false;
             if (ix_pending && hipEventQuery((hipEvent_t)ix_ev) == hipSuccess) { memcpy(&hd, h_ix.p, sizeof(hd)); ix_pending = false; have = true; }
             if (!have && ix_seq_cap == 0) {
-                HIP_TRY(hipMemcpyAsync(&hd, j.d_index, sizeof(hd), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(&hd, d_index, sizeof(hd), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 have = true;
             }
             if (have && hd.magic == IX_MAGIC && hd.stride == IX_STRIDE && hd.total_seqs <= (uint64_t)hd.total_entries * (IX_STRIDE + 1) &&
-                hd.total_entries <= (j.index_size - sizeof(IxHeader)) / sizeof(IxEntry)) {
+                hd.total_entries <= (index_size - sizeof(IxHeader)) / sizeof(IxEntry)) {
                 if (hd.total_seqs > ix_seq_cap) ix_seq_cap = (size_t)hd.total_seqs + hd.total_seqs / 4 + 4096;      // (a quarter of slack: the next stream differs)
                 if (hd.total_entries > ix_entries_hint) ix_entries_hint = hd.total_entries + hd.total_entries / 4;
             }
@@ -304,15 +340,15 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 const uint32_t lk = j.linked ? 1u : 0u;
                 unsigned long long* iprof = (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr);
                 tick(8, false);
-                hipLaunchKernelGGL(k_check_index, dim3(1), dim3(64), 0, st, (const void*)j.d_index, (uint64_t)j.index_size, n_max, cpb, chunk,
+                hipLaunchKernelGGL(k_check_index, dim3(1), dim3(64), 0, st, (const void*)d_index, (uint64_t)index_size, n_max, cpb, chunk,
                                    (uint64_t)ix_seq_cap, (uint32_t*)seqcnt.p);
                 uint32_t n_lanes = ix_entries_hint > n_max ? ix_entries_hint : n_max;           // (grid-stride inside: a hint is enough)
                 hipLaunchKernelGGL(k_parse_indexed, dim3((n_lanes + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap,
-                                   (const BlockOut*)tbl, (const void*)j.d_index, n_max, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, lk);
+                                   (const BlockOut*)tbl, (const void*)d_index, n_max, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, lk);
                 uint32_t* dsrc = (uint32_t*)((uint8_t*)desc.p + dsrc_at);
                 if (getenv("LZ4F_MI355X_NO_RESOLVE")) dsrc = nullptr;
                 else
-                    hipLaunchKernelGGL(k_resolve_direct, dim3(n_max, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u), dim3(256), 0, st, j.d_index, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, (const SeqDesc*)desc.p,
+                    hipLaunchKernelGGL(k_resolve_direct, dim3(n_max, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u), dim3(256), 0, st, d_index, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, (const SeqDesc*)desc.p,
                                        dsrc, (uint32_t*)seqcnt.p, iprof ? 1u : 0u, lk);
                 if (iprof) {                                                   // developer aid: how many matches are direct
                     uint32_t c[8];
@@ -327,16 +363,16 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 const uint32_t n_wg = (n_max + group - 1) / group;
                 if (j.block_size <= (1u << 20))
                     hipLaunchKernelGGL(k_copy_indexed<FzCfg<4>>, dim3(n_wg), dim3(64 * 4), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_max,
-                                       j.d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done, group);
+                                       d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done, group);
                 else
                     hipLaunchKernelGGL(k_copy_indexed<FzCfg<8>>, dim3(n_wg), dim3(64 * 8), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_max,
-                                       j.d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done, group);
+                                       d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done, group);
                 tick(9, true);
                 if (iprof && j.linked) { uint32_t y[4] = {0, 0, 0, 0}; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(y, (uint32_t*)seqcnt.p + 20, 16, hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "indexed (linked): blocks that found the block in front at state 3: %u (of those, had to wait for all of it: %u); blocks with set-aside matches %u (block in front already done: %u)\n", y[0], y[1], y[2], y[3]); }
                 indexed = true;
             }
             // this call's header for the next call (no wait here)
-            HIP_TRY(hipMemcpyAsync(h_ix.p, j.d_index, sizeof(IxHeader), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(h_ix.p, d_index, sizeof(IxHeader), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipEventRecord((hipEvent_t)ix_ev, st));
             ix_pending = true;
         }
