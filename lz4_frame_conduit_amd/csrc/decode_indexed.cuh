@@ -68,7 +68,7 @@ __global__ void k_check_index(const void* __restrict__ ix, uint64_t ix_size, uin
 // a wrong index can make the call fall back, never change the bytes that come out.
 __device__ __forceinline__ void parse_entry(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
                                             const void* __restrict__ ix, uint32_t n_blocks, uint32_t n_entries,
-                                            SeqDesc* __restrict__ desc, uint64_t desc_cap, uint32_t* __restrict__ flags, uint32_t gid, uint32_t linked)
+                                            SeqDesc* __restrict__ desc, uint64_t desc_cap, uint32_t* __restrict__ flags, uint32_t gid, uint32_t linked, uint64_t hist0)
 {
     const IxBlock* blocks = ix_blocks(ix);
     if (gid < n_blocks) {
@@ -155,7 +155,7 @@ __device__ __forceinline__ void parse_entry(const uint8_t* __restrict__ frame, u
         if (mlen) {
             const uint32_t dm = op + lit;
             // a source in front of the block: only in a linked frame, and only as far as there is output before this block
-            if (off > dm && (!linked || (uint64_t)(off - dm) > e.dst_off)) { bad = true; break; }
+            if (off > dm && (!linked || (uint64_t)(off - dm) > e.dst_off + hist0)) { bad = true; break; }      // (hist0: output of an earlier call in front of this frame part)
             const uint32_t s0 = dm - off;
             uint32_t msrc = 0xFFFFFFFFu;
             if (mlen <= off && off <= dm) {
@@ -175,14 +175,14 @@ __device__ __forceinline__ void parse_entry(const uint8_t* __restrict__ frame, u
 
 __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
                                                        const void* __restrict__ ix, uint32_t n_blocks,
-                                                       SeqDesc* __restrict__ desc, uint32_t* __restrict__ flags, uint32_t linked)
+                                                       SeqDesc* __restrict__ desc, uint32_t* __restrict__ flags, uint32_t linked, uint64_t hist0)
 {
     if (*flags) return;
     const uint32_t n_entries = flags[8];
     const uint64_t desc_cap = flags[9];
     const uint32_t n_lanes = n_entries > n_blocks ? n_entries : n_blocks;
     for (uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n_lanes; gid += gridDim.x * blockDim.x)
-        parse_entry(frame, frame_cap, table, ix, n_blocks, n_entries, desc, desc_cap, flags, gid, linked);
+        parse_entry(frame, frame_cap, table, ix, n_blocks, n_entries, desc, desc_cap, flags, gid, linked, hist0);
 }
 
 
@@ -396,7 +396,7 @@ template <class C>
 __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(const uint8_t* __restrict__ frame, uint8_t* dst, BlockOut* __restrict__ table,
                                                                    const ResultRec* __restrict__ res, uint32_t n_max, void* __restrict__ ix,
                                                                    const SeqDesc* __restrict__ desc, const uint32_t* __restrict__ dsrc, uint32_t* __restrict__ flags,
-                                                                   unsigned long long* prof, uint32_t linked, uint32_t* __restrict__ done, uint32_t group)
+                                                                   unsigned long long* prof, uint32_t linked, uint32_t* __restrict__ done, uint32_t group, uint64_t hist0)
 {   // group: consecutive blocks per workgroup (1 except for small blocks of a linked frame, see below)
     __shared__ FzShared<C> sh;
     if (res->status != ST_OK || *flags) return;                              // index unusable: the generic kernel launched behind does the work
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(cons
             }
         } else {
             const IxBlock blk = ix_blocks(ix)[b];
-            got = fz_decode_block<C, true>(sh, frame + e.src_off, csz, dst + e.dst_off, e.dst_size, e.dst_off, frame, prof, desc + blk.seq_base, blk.nseq,
+            got = fz_decode_block<C, true>(sh, frame + e.src_off, csz, dst + e.dst_off, e.dst_size, e.dst_off + hist0, frame, prof, desc + blk.seq_base, blk.nseq,
                                            dsrc ? dsrc + blk.seq_base : nullptr, e.src_off, g > 0 ? done + (g - 1) : nullptr, own_front, b == b0);
         }
         if (got < 0) failed = true;

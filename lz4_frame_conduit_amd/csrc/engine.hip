@@ -274,7 +274,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         bool indexed = false;
         void* d_index = j.d_index; size_t index_size = j.index_size;
         bool self_indexed = false;
-        if (mode == 'f' && j.linked && !j.d_index && j.hist0 == 0 && n_max >= 2 && !getenv("LZ4F_MI355X_NO_INDEX") && !getenv("LZ4F_MI355X_NO_SELFINDEX")) {
+        if (mode == 'f' && j.linked && !j.d_index && j.hist0 <= 65536 && n_max >= 2 && !getenv("LZ4F_MI355X_NO_INDEX") && !getenv("LZ4F_MI355X_NO_SELFINDEX")) {
             // A linked frame without an index (a foreign one: the reference's default output): make the index here - a lane per block
             // walks the payload (parsing needs no history), a scan places the blocks - and take the same kernels as with the
             // compressor's index.  Two host synchronisations (the totals size the buffers); anything odd leaves the frame to the
@@ -309,7 +309,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             }
         }
         // (linked frames: only with a table that has every block's output position - the compressor's, or the one just made)
-        if (mode == 'f' && d_index && index_size >= sizeof(IxHeader) && (!j.linked || self_indexed || ((j.d_table || j.table_in_place) && j.hist0 == 0)) &&
+        if (mode == 'f' && d_index && index_size >= sizeof(IxHeader) && (!j.linked || self_indexed || ((j.d_table || j.table_in_place) && j.hist0 <= 65536)) &&
             !getenv("LZ4F_MI355X_NO_INDEX")) {
             // Descriptors from the compressor's sequence index: a lane per entry parses, a lane per sequence resolves direct
             // matches, a workgroup per block copies.  The descriptor workspace is sized from the index header.  The first
@@ -344,7 +344,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                                    (uint64_t)ix_seq_cap, (uint32_t*)seqcnt.p);
                 uint32_t n_lanes = ix_entries_hint > n_max ? ix_entries_hint : n_max;           // (grid-stride inside: a hint is enough)
                 hipLaunchKernelGGL(k_parse_indexed, dim3((n_lanes + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap,
-                                   (const BlockOut*)tbl, (const void*)d_index, n_max, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, lk);
+                                   (const BlockOut*)tbl, (const void*)d_index, n_max, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, lk, (uint64_t)j.hist0);
                 uint32_t* dsrc = (uint32_t*)((uint8_t*)desc.p + dsrc_at);
                 if (getenv("LZ4F_MI355X_NO_RESOLVE")) dsrc = nullptr;
                 else
@@ -363,10 +363,10 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 const uint32_t n_wg = (n_max + group - 1) / group;
                 if (j.block_size <= (1u << 20))
                     hipLaunchKernelGGL(k_copy_indexed<FzCfg<4>>, dim3(n_wg), dim3(64 * 4), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_max,
-                                       d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done, group);
+                                       d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done, group, (uint64_t)j.hist0);
                 else
                     hipLaunchKernelGGL(k_copy_indexed<FzCfg<8>>, dim3(n_wg), dim3(64 * 8), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_max,
-                                       d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done, group);
+                                       d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done, group, (uint64_t)j.hist0);
                 tick(9, true);
                 if (iprof && j.linked) { uint32_t y[4] = {0, 0, 0, 0}; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(y, (uint32_t*)seqcnt.p + 20, 16, hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "indexed (linked): blocks that found the block in front at state 3: %u (of those, had to wait for all of it: %u); blocks with set-aside matches %u (block in front already done: %u)\n", y[0], y[1], y[2], y[3]); }
                 indexed = true;

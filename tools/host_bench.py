@@ -9,7 +9,7 @@ n = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024) << 20
 bsid = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 L = _ffi.lib()
 src = np.ascontiguousarray(datagen.synth50(n, 1234))
-prefs = conduit.make_preferences(blockSizeID=bsid, blockMode=1)
+prefs = conduit.make_preferences(blockSizeID=bsid, blockMode=0 if os.environ.get('LINKED') else 1)
 bound = L.lz4f_mi355x_compressFrameBound(n, ctypes.byref(prefs))
 dst = np.empty(bound, dtype=np.uint8); back = np.empty(n + 8, dtype=np.uint8)
 def ptr(a): return a.ctypes.data_as(ctypes.c_void_p)
