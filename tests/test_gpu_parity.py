@@ -499,9 +499,18 @@ def test_linked_frames_windowed_and_fallback(L, named_inputs):
         (oracle.conduit_compress(st, oracle.mkprefs(bsid=4, indep=0, autoflush=1), 50000), st),                # short blocks: fallback path
         (oracle.conduit_compress(named_inputs["random10m"][:400000] + st[:300000], oracle.mkprefs(bsid=4, indep=0)), named_inputs["random10m"][:400000] + st[:300000]),  # stored blocks inside
     ]
-    for i, (frame, want) in enumerate(cases):
-        out, used = gpu_decompress_frame(L, frame, len(want) + 8)
-        assert used == len(frame) and sha(out) == sha(want), i
+    import os
+    # three decoders for a linked frame that arrives without an index: the one that indexes it itself (default), the window
+    # kernel (what the former falls back to, and takes dense frames by itself), the single-workgroup generic kernel
+    for env in ({}, {"LZ4F_MI355X_NO_SELFINDEX": "1"}, {"LZ4F_MI355X_NO_SELFINDEX": "1", "LZ4F_MI355X_NO_WINDOW": "1"}):
+        os.environ.update(env)
+        try:
+            for i, (frame, want) in enumerate(cases):
+                out, used = gpu_decompress_frame(L, frame, len(want) + 8)
+                assert used == len(frame) and sha(out) == sha(want), (i, env)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
     # malformed linked frames: same verdicts as the oracle
     base = cases[0][0]
     for pos in (200, 5000, 70000, 140000, len(base) // 2):
