@@ -1,4 +1,5 @@
-// decode_indexed.cuh -- decode of big independent blocks with a SEQUENCE INDEX from the compressor
+// decode_indexed.cuh -- decode of big independent blocks and of linked frames through a SEQUENCE INDEX: the compressor's,
+// or (linked frames that come without one) an index the decoder makes itself
 // (DESIGN.md section 8 item 1).
 //
 // The scalar parser of decode_fused.cuh costs ~200 scalar instructions per sequence and a CU has one scalar unit:
@@ -18,6 +19,10 @@
 //                     the block's descriptors, following plain matches a few hops) become direct as well
 //   k_copy_indexed    one workgroup per block: the copier waves of decode_fused.cuh, fed with those descriptors by
 //                     wave 0 instead of by a parser wave; only the matches that are not direct form a chain.
+//                     Linked frames: a workgroup per group of consecutive small blocks; chain matches that read another
+//                     workgroup's output are set aside and replayed when that one is far enough.
+//   k_selfindex_walk / k_selfindex_scan   linked frames without an index: a lane per block walks the payload (parsing
+//                     needs no history), a scan places the blocks, the entries are written - then everything above
 #pragma once
 #include "common.cuh"
 #include "decode.cuh"
