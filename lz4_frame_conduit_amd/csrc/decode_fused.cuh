@@ -39,7 +39,10 @@ constexpr uint32_t FZ_OVER = 576;                // >= the parser's 520-byte reg
 constexpr int      FZ_MATCH_SET = 3;
 constexpr uint32_t FZ_SRC_BIAS = 1u << 22;       // direct matches: payload position relative to the block's payload + this (== IX_SRC_BIAS)
 constexpr uint32_t FZ_PEND = 32;                // linked, fed: matches set aside until the block in front is done
-constexpr uint32_t FZ_PREV_SPIN_MAX = 1u << 22; // polls of the previous block's "done" word before giving up (-> generic decoder)            // match copies per register set (two sets in flight)
+constexpr uint64_t FZ_PREV_WAIT_TICKS = 300ull * 100000000ull;  // 300 s of the 100 MHz clock: how long a workgroup waits for the one in front before
+                                                                // it gives up (-> generic decoder).  A safety net (they are dispatched in order) that has
+                                                                // to outlast a whole dense frame whose groups run one after the other.
+__device__ __forceinline__ bool fz_wait_expired(uint64_t t0) { return __builtin_amdgcn_s_memrealtime() - t0 > FZ_PREV_WAIT_TICKS; }            // match copies per register set (two sets in flight)
 
 template <class C>
 struct alignas(16) FzShared {
@@ -506,9 +509,9 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
                         // no room on the list: wait for the block in front after all (workgroups are dispatched in block order, so it
                         // is running or finished; the poll has a budget), replay what is on the list, go on without one
                         uint32_t v = 0;                                       // (1 = all of it done, 2 = failed; 3 = only its main pass: not enough here)
-                        for (uint32_t spin = 0; spin < FZ_PREV_SPIN_MAX; spin++) {
+                        for (const uint64_t t0 = __builtin_amdgcn_s_memrealtime();;) {
                             v = __hip_atomic_load(prev_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (v == 1u || v == 2u) break;
+                            if (v == 1u || v == 2u || fz_wait_expired(t0)) break;
                             __builtin_amdgcn_s_sleep(8);
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

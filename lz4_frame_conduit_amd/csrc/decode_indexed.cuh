@@ -311,7 +311,6 @@ __global__ __launch_bounds__(1024) void k_selfindex_scan(BlockOut* __restrict__ 
 // The descriptors are only read here; the answer goes to dsrc[i] (IX_NOT_DIRECT = none) and the feeder wave merges it in.
 constexpr uint32_t IXR_HOPS = 6;
 constexpr uint32_t IXL_PUB = 8;                                // set-aside destinations a block publishes for the block behind (more: that one waits for all of it)
-constexpr uint32_t IXL_CHAIN_FRACTION = 8;                     // linked frames: the indexed kernels take the frame if at most 1/8 of its sequences stay on the chain
 constexpr uint32_t IX_NOT_DIRECT = 0xFFFFFFFFu;
 // In a linked frame the source may start in the block before (offsets reach 64 KiB back): the search then runs over that
 // block's descriptors - or, if that block is stored, its payload IS its output.  The answer is the payload position
@@ -410,10 +409,11 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(cons
     const uint32_t b0 = g * group;
     if (b0 >= n) return;
     const uint32_t b1 = (b0 + group < n) ? b0 + group : n;
-    // Linked frame with most of its matches on the chain: the blocks then run one after the other (each waits for the block in
-    // front), and a workgroup per block polling its neighbour is the slowest way to walk one chain (measured: 30x slower
-    // than the window kernel on such data).  Leave those to decode_linked.cuh.
-    if (linked && (uint64_t)flags[10] * IXL_CHAIN_FRACTION > flags[9]) { if (g == 0 && tid == 0) atomicOr(flags, 4u); return; }
+    // (A linked frame with most of its matches on the chain runs its groups one after the other - each waits for the one in front.
+    // That is still 1.4-2x faster than the window kernel on such data (text 64 MiB: 2.5 vs 3.4 s; `datagen.structured` 48 MiB:
+    // 0.15 vs 0.30 s), so there is no gate any more; LZ4F_MI355X_CHAIN_GATE=n leaves frames with more than 1/n of their
+    // sequences on the chain to decode_linked.cuh.)
+    if (linked > 1u && (uint64_t)flags[10] * (linked >> 1) > flags[9]) { if (g == 0 && tid == 0) atomicOr(flags, 4u); return; }
     if (!linked) {                                                           // (group == 1)
         const uint32_t b = b0;
         const BlockOut e = table[b];
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(cons
             uint32_t v = 0;
             auto poll = [&](bool all) {
                 // (relaxed polls, one acquire at the end: an acquire per poll would empty this CU's vector cache every time)
-                for (uint32_t spin = 0; spin < FZ_PREV_SPIN_MAX; spin++) {
+                for (const uint64_t t0 = __builtin_amdgcn_s_memrealtime(); !fz_wait_expired(t0);) {
                     v = __hip_atomic_load(pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (v == 1u || v == 2u || (v == 3u && !all)) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); return; }
                     __builtin_amdgcn_s_sleep(8);

@@ -337,7 +337,8 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 if (desc.ensure(dsrc_at + (ix_seq_cap + 64) * 4) || seqcnt.ensure(256 + (size_t)n_max * (8 + 8 * IXL_PUB))) return make_err(LZ4F_ERROR_allocation_failed);
                 HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 64 + (j.linked ? 192 + (size_t)n_max * 8 : 0), st));      // flags (+ per block of a linked frame: the "done" word and the count of published ranges)
                 uint32_t* done = (uint32_t*)seqcnt.p + 64;
-                const uint32_t lk = j.linked ? 1u : 0u;
+                uint32_t lk = j.linked ? 1u : 0u;                                  // (bits 1..: chain gate, see k_copy_indexed)
+                if (j.linked) if (const char* gs = getenv("LZ4F_MI355X_CHAIN_GATE")) { const int gv = atoi(gs); if (gv > 0 && gv < (1 << 20)) lk |= (uint32_t)gv << 1; }
                 unsigned long long* iprof = (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr);
                 tick(8, false);
                 hipLaunchKernelGGL(k_check_index, dim3(1), dim3(64), 0, st, (const void*)d_index, (uint64_t)index_size, n_max, cpb, chunk,
