@@ -385,11 +385,194 @@ __global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, c
             if (count_it) atomicAdd(flags + (found != IX_NOT_DIRECT ? 5 : 6), 1u);
             if (count_it && linked && found == IX_NOT_DIRECT && off > dm) atomicAdd(flags + 11, 1u);
         } else if (count_it && ml) atomicAdd(flags + 4, 1u);
-        if (linked) {                                           // how long is the chain that stays? (one atomic per wave)
+        {                                                       // how long is the chain that stays? (one atomic per wave)
             const uint64_t m = __ballot(ml != 0 && !(d.w >> 31) && found == IX_NOT_DIRECT);
             if (m && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) atomicAdd(flags + 10, (uint32_t)__builtin_popcountll(m));
         }
         dsrc[blk.seq_base + i] = found;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DENSE frames (most sequences end in a match that is not direct: text).  The copier workgroups walk such a block as the one
+// chain it is, ~0.35 us per sequence.  But every output byte originates in a literal: follow a match byte back through the
+// descriptors - source position -> the sequence that produced it -> its literal run (done) or its match (one more hop) - and
+// the whole frame is gathers, no chain.  A thread per 16 output bytes traces the first byte, gets the origin and how far the
+// bytes behind it share it (the shortest remainder of a run along the way), copies that many, traces again.
+//   k_dense_gate      decides (on the device) from k_resolve_direct's count of matches left on the chain
+//   k_build_postab    per block: output position / 64 -> sequence (so that a hop is a read and a few steps, not a 12-step binary
+//                     search), and the check that the descriptors tile the block's output
+//   k_trace_copy      the gathers
+constexpr uint32_t IXT_MAX_HOPS = 4096;                         // then the frame goes to the generic kernels
+constexpr uint32_t IXT_FLAG = 24;                               // flags[IXT_FLAG] != 0: dense, traced
+
+__global__ void k_dense_gate(uint32_t* __restrict__ flags, uint32_t on)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) flags[IXT_FLAG] = (on && !*flags && (on > 1 || (uint64_t)flags[10] * 2 > flags[9])) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_build_postab(void* __restrict__ ix, const BlockOut* __restrict__ table, const ResultRec* __restrict__ res, uint32_t n_max,
+                                                      const SeqDesc* __restrict__ desc, uint32_t* __restrict__ postab, uint32_t* __restrict__ flags)
+{
+    if (res->status != ST_OK || *flags || !flags[IXT_FLAG]) return;
+    const uint32_t b = blockIdx.x;
+    const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    if (b >= n) return;
+    const BlockOut e = table[b];
+    if (e.word >> 31) return;
+    const IxBlock blk = ix_blocks((const void*)ix)[b];
+    if ((uint64_t)blk.seq_base + blk.nseq > flags[9] || (e.dst_off & 63u)) { atomicOr(flags, 2u); return; }
+    const SeqDesc* bd = desc + blk.seq_base;
+    uint32_t* T = postab + (e.dst_off >> 6);
+    for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < blk.nseq; i += gridDim.y * 256) {
+        const SeqDesc d = bd[i];
+        const uint32_t op = d.z, end = op + (d.y & 0xFFFFFFu) + (d.w & 0xFFFFFFu);
+        // the descriptors must tile [0, size): first at 0, each where the one before ends, the last at the block's size
+        const bool okay = (i == 0 ? op == 0 : true) && (i + 1 < blk.nseq ? bd[i + 1].z == end : end == e.dst_size) && end >= op && end <= e.dst_size;
+        if (!okay) { atomicOr(flags, 2u); continue; }
+        for (uint32_t k = (op + 63u) >> 6; (k << 6) < end; k++) T[k] = i;                 // I hold output positions 64k in [op, end)
+    }
+}
+
+// Depth: a phrase of a text is a copy of its last occurrence, which is a copy of the one before ... - traced to the literal that
+// is thousands of hops.  So a trace stays inside its REGION (64 KiB of output): a source in an earlier region is read from the
+// output itself, once that region is complete (a count of bytes per region, added to by each workgroup behind a release; the
+// workgroups of earlier regions have lower indexes, so they are running or done - the same forward-progress rule as
+// k_copy_indexed's).  Regions of one block therefore finish in order, ~5 us each; independent blocks have their regions
+// interleaved over the grid (region k of every block, then region k+1 ...) so that all blocks advance together.
+constexpr uint32_t IXT_TB = 16;                                  // output bytes per thread
+constexpr uint32_t IXT_WG_BYTES = 256 * IXT_TB;
+constexpr uint32_t IXT_REGION_LOG = 12;                          // a region = a workgroup's bytes
+constexpr uint32_t IXT_REGION = 1u << IXT_REGION_LOG;
+static_assert(IXT_REGION == IXT_WG_BYTES, "one workgroup per region");
+
+__global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint8_t* dst, const BlockOut* __restrict__ table,
+                                                    const ResultRec* __restrict__ res, uint32_t n_max, void* __restrict__ ix, const SeqDesc* __restrict__ desc,
+                                                    const uint32_t* __restrict__ dsrc, const uint32_t* __restrict__ postab, uint32_t* flags,
+                                                    uint32_t linked, uint32_t block_size, uint64_t hist0, uint32_t* region_cnt, uint32_t count_it)
+{
+    __shared__ uint32_t go;
+    if (threadIdx.x == 0) go = (res->status == ST_OK && !__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && flags[IXT_FLAG]) ? 1u : 0u;
+    __syncthreads();
+    if (!go) return;
+    const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    // which 4 KiB of the output is this workgroup's
+    uint64_t wg_pos;
+    if (linked || block_size <= IXT_REGION) wg_pos = (uint64_t)blockIdx.x * IXT_WG_BYTES;
+    else {
+        const uint32_t per_k = n_max * (IXT_REGION / IXT_WG_BYTES);
+        const uint32_t k = blockIdx.x / per_k, rem = blockIdx.x % per_k;
+        wg_pos = (uint64_t)(rem / (IXT_REGION / IXT_WG_BYTES)) * block_size + (uint64_t)k * IXT_REGION + (uint64_t)(rem % (IXT_REGION / IXT_WG_BYTES)) * IXT_WG_BYTES;
+    }
+    const uint64_t gpos = wg_pos + threadIdx.x * IXT_TB;
+    const uint32_t my_region = (uint32_t)(wg_pos >> IXT_REGION_LOG);
+    const uint32_t b = (uint32_t)(wg_pos / block_size);
+    bool bad = false;
+    uint32_t wg_bytes = 0;
+    if (b < n) {
+        const BlockOut e0 = table[b];
+        if (e0.dst_off != (uint64_t)b * block_size) bad = true;                             // (all blocks but the last are full: checked when the index was made)
+        else {
+            const uint64_t wg_rel = wg_pos - e0.dst_off;
+            wg_bytes = wg_rel >= e0.dst_size ? 0u : (e0.dst_size - wg_rel < IXT_WG_BYTES ? (uint32_t)(e0.dst_size - wg_rel) : IXT_WG_BYTES);
+        }
+        const uint32_t i0 = (uint32_t)(gpos - e0.dst_off);
+        const IxBlock* blocks = ix_blocks((const void*)ix);
+        uint8_t* out = dst + gpos;
+        const uint32_t want = (bad || i0 >= e0.dst_size) ? 0u : (e0.dst_size - i0 < IXT_TB ? e0.dst_size - i0 : IXT_TB);
+        uint32_t cb_have = 0xFFFFFFFFu;                                 // (the block whose table entries are in registers)
+        BlockOut e = e0;
+        IxBlock blk = {0, 0, 0, 0};
+        uint32_t ready_region = 0xFFFFFFFFu;                            // the last region this thread has seen complete
+        // One loop, one hop per turn: where does output byte gpos + got come from, and how many bytes behind it come from right
+        // behind that?  A lane whose trace ends copies the piece and starts on its next one in the same turn (with a loop
+        // per piece the wave would wait for its deepest trace once per piece).
+        uint32_t got = 0, hops = 0, sq_next = 0xFFFFFFFFu, n_turns = 0, n_pieces = 0, n_fromout = 0;
+        uint64_t g = gpos;                                              // (position in the frame's output)
+        uint32_t span = want;
+        while (got < want && !bad) {
+            const uint8_t* origin = nullptr;
+            int kind = 0;                                               // 1: in the payload, 2: in the output (earlier region or call)
+            bool moved = false;
+            n_turns++;
+            do {
+                const uint32_t cb = (uint32_t)(g / block_size);
+                if (cb != cb_have) { e = table[cb]; blk = blocks[cb]; cb_have = cb; }
+                const uint32_t j = (uint32_t)(g - e.dst_off);
+                if (e.dst_off != (uint64_t)cb * block_size || j >= e.dst_size) break;
+                if (e.word >> 31) { const uint32_t left = e.dst_size - j; if (left < span) span = left; origin = frame + e.src_off + j; kind = 1; break; }
+                const SeqDesc* bd = desc + blk.seq_base;
+                // the sequence that holds j: the table says where to start; four descriptors at once (one latency), the last
+                // of them that begins at or before j is it - or, if j is behind its end, the search goes on next turn
+                uint32_t sq = sq_next != 0xFFFFFFFFu ? sq_next : postab[(e.dst_off >> 6) + (j >> 6)];
+                sq_next = 0xFFFFFFFFu;
+                if (sq >= blk.nseq) break;
+                const uint32_t last = blk.nseq - 1;
+                const SeqDesc c0 = bd[sq], c1 = bd[sq + 1 < last ? sq + 1 : last], c2 = bd[sq + 2 < last ? sq + 2 : last], c3 = bd[sq + 3 < last ? sq + 3 : last];
+                SeqDesc d = c0;
+                const uint32_t sq0 = sq;
+                if (c1.z <= j) { d = c1; sq = sq0 + 1 < last ? sq0 + 1 : last; }
+                if (c2.z <= j) { d = c2; sq = sq0 + 2 < last ? sq0 + 2 : last; }
+                if (c3.z <= j) { d = c3; sq = sq0 + 3 < last ? sq0 + 3 : last; }
+                const uint32_t lit = d.y & 0xFFFFFFu, ml = d.w & 0xFFFFFFu, op = d.z, dm = op + lit;
+                const uint32_t f24 = (d.x >> 24) | ((d.y >> 24) << 8) | (((d.w >> 24) & 0x7Fu) << 16);
+                if (j < op) break;
+                if (j >= dm + ml) { if (sq >= last) break; sq_next = sq + 1; moved = true; break; }
+                if (j < dm) {                                          // a literal: the origin
+                    const uint32_t left = dm - j; if (left < span) span = left;
+                    origin = frame + e.src_off + (d.x & 0xFFFFFFu) + (j - op); kind = 1;
+                    break;
+                }
+                const uint32_t r = j - dm;
+                const uint32_t ds = (d.w >> 31) ? f24 : dsrc[blk.seq_base + sq];
+                if (ds < (1u << 23)) {                                 // a direct match: its bytes are in the payload
+                    const uint32_t left = ml - r; if (left < span) span = left;
+                    origin = frame + e.src_off + ((int64_t)ds - (int64_t)IX_SRC_BIAS) + r; kind = 1;
+                    break;
+                }
+                const uint32_t off = f24 & 0xFFFFu;
+                if (off == 0) break;
+                uint32_t rr = r, left = ml - r;
+                if (off <= r) rr = r % off;                            // the match replicates its own output: fold
+                if (off < ml && off - rr < left) left = off - rr;      // (a folded run repeats every `off` bytes)
+                if (left < span) span = left;
+                const uint64_t back = (uint64_t)off + (r - rr);
+                if (back > g) {                                        // before this call's output: the history (linked frames)
+                    if (!linked || back - g > hist0) break;
+                    if (back - g < span) span = (uint32_t)(back - g);
+                    origin = dst - (back - g); kind = 2;
+                    break;
+                }
+                if (!linked && g - back < e.dst_off) break;            // (independent blocks: nothing in front)
+                g -= back;
+                moved = true;
+                const uint32_t rg = (uint32_t)(g >> IXT_REGION_LOG);
+                if (rg != my_region) {                                 // in an earlier region: if that one is complete, its bytes; else on through it
+                    if (rg > my_region) { moved = false; break; }
+                    if (rg == ready_region || __hip_atomic_load(region_cnt + rg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= IXT_REGION) {
+                        if (rg != ready_region) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); ready_region = rg; }
+                        const uint32_t to_end = IXT_REGION - (uint32_t)(g & (IXT_REGION - 1));
+                        if (to_end < span) span = to_end;
+                        origin = dst + g; kind = 2;
+                    }
+                }
+            } while (false);
+            if (origin) {
+                if (span == 0 || (kind == 1 && (origin < frame || origin + span > frame + frame_cap))) { bad = true; break; }
+                for (uint32_t q = 0; q < span; q++) out[got + q] = origin[q];
+                got += span; n_pieces++; n_fromout += kind == 2;
+                g = gpos + got; span = want - got; hops = 0;
+            } else if (!moved || ++hops >= IXT_MAX_HOPS) bad = true;
+        }
+        if (count_it) { atomicAdd((unsigned long long*)(flags + 26), (unsigned long long)n_turns); atomicAdd(flags + 28, n_pieces); atomicAdd(flags + 29, n_fromout); atomicMax(flags + 30, n_turns); }
+    }
+    if (bad) atomicOr(flags, 2u);
+    // this workgroup's bytes are in memory: count them into the region
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0 && wg_bytes) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __hip_atomic_fetch_add(region_cnt + my_region, wg_bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -403,7 +586,7 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(cons
                                                                    unsigned long long* prof, uint32_t linked, uint32_t* __restrict__ done, uint32_t group, uint64_t hist0)
 {   // group: consecutive blocks per workgroup (1 except for small blocks of a linked frame, see below)
     __shared__ FzShared<C> sh;
-    if (res->status != ST_OK || *flags) return;                              // index unusable: the generic kernel launched behind does the work
+    if (res->status != ST_OK || *flags || flags[IXT_FLAG]) return;           // index unusable: the generic kernel launched behind does the work; dense: traced
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
     const uint32_t g = blockIdx.x, tid = threadIdx.x;
     const uint32_t b0 = g * group;

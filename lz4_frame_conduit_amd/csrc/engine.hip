@@ -357,6 +357,27 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                         fprintf(stderr, "indexed: flags %u, matches direct after parse %u, resolved %u, left to the chain %u\n", c[0], c[4], c[5], c[6]);
                     uint32_t x[6] = {0, 0, 0, 0, 0, 0}; if (hipMemcpy(x, (uint32_t*)seqcnt.p + 10, 24, hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "indexed (linked): %u matches stay on the chain, %u of them reach into the block in front (%u blocks); not resolved because: beyond one block %u, source straddles two runs %u, run-length source %u, hop limit %u\n", x[0], x[1], n_max, x[2], x[3], x[4], x[5]);
                 }
+                // dense frames (text): no chain at all, every output byte traced to its literal (see k_trace_copy)
+                {
+                    const uint64_t trace_span = (uint64_t)n_max * j.block_size;            // (the last block may be short)
+                    const bool trace_on = !getenv("LZ4F_MI355X_NO_TRACE") && dsrc && (j.block_size & 63u) == 0 && !postab.ensure((size_t)(trace_span >> 6) * 4 + 512 + ((size_t)(trace_span >> IXT_REGION_LOG) + 4) * 4);
+                    // (independent blocks have block-level parallelism: with many of them the copier workgroups, a chain per block, are
+                    // faster than tracing every byte ~100 hops deep; measured break-even ~64 blocks of text)
+                    const uint32_t gate = !trace_on ? 0u : getenv("LZ4F_MI355X_TRACE_ALWAYS") ? 2u : (j.linked || n_max <= 48) ? 1u : 0u;
+                    hipLaunchKernelGGL(k_dense_gate, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, gate);
+                    if (gate) {
+                        hipLaunchKernelGGL(k_build_postab, dim3(n_max, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u), dim3(256), 0, st, d_index, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max,
+                                           (const SeqDesc*)desc.p, (uint32_t*)postab.p, (uint32_t*)seqcnt.p);
+                        const uint64_t n_thr = (trace_span + IXT_TB - 1) / IXT_TB;
+                        uint32_t trace_lds = 0; if (const char* tl = getenv("LZ4F_MI355X_TRACE_LDS")) trace_lds = (uint32_t)atoi(tl);
+                        uint32_t* region_cnt = (uint32_t*)((uint8_t*)postab.p + (((size_t)(trace_span >> 6) * 4 + 255) & ~(size_t)255));
+                        if (hipMemsetAsync(region_cnt, 0, ((size_t)(trace_span >> IXT_REGION_LOG) + 2) * 4, st) != hipSuccess) return make_err(LZ4F_ERROR_GENERIC);
+                        hipLaunchKernelGGL(k_trace_copy, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), trace_lds, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, (const BlockOut*)tbl,
+                                           (const ResultRec*)d_res, n_max, d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (const uint32_t*)postab.p, (uint32_t*)seqcnt.p,
+                                           lk & 1u, (uint32_t)j.block_size, (uint64_t)j.hist0, region_cnt, iprof ? 1u : 0u);
+                        if (iprof) { uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(t, (uint32_t*)seqcnt.p + 24, 32, hipMemcpyDeviceToHost) == hipSuccess && t[0]) fprintf(stderr, "traced: %llu turns for %u pieces (%u read from the output), deepest thread %u turns\n", (unsigned long long)t[2] | ((unsigned long long)t[3] << 32), t[4], t[5], t[6]); }
+                    }
+                }
                 tick(8, true);
                 tick(9, false);
                 // (linked frames of small blocks: a workgroup takes a group of consecutive blocks - see k_copy_indexed)

@@ -54,6 +54,7 @@ struct lz4f_mi355x_engine {
     bool  own_stream = false;
     lz4f::DevBuf info, recs, table, blk_bytes, res, bad;   // workspace of the block kernels
     lz4f::DevBuf selfix, selfcnt;                          // linked frames without an index: the one made here, and its per-block counts
+    lz4f::DevBuf postab;                                   // dense frames: output position / 64 -> sequence (k_build_postab)
     lz4f::DevBuf desc, seqcnt;                             // two-kernel decode: sequence descriptors, per-block counts
     lz4f::DevBuf d_in, d_out;                              // staging for the host-pointer paths
     lz4f::PinBuf h_in, h_out, h_small;

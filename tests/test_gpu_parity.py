@@ -579,6 +579,42 @@ def test_indexed_decode_same_bytes_as_generic(L):
     eng.close()
 
 
+def test_traced_decode_same_bytes(L, monkeypatch):
+    """Dense frames (text) are decoded by tracing every output byte back to its literal (k_trace_copy) instead of walking the
+    chain.  Forced on here for every input and framing, history included: same bytes as the source, and a wrong index is
+    still noticed (the tracer validates what it follows and hands over to the generic kernels)."""
+    import torch
+    from lz4_frame_conduit_amd.device import Engine
+    monkeypatch.setenv("LZ4F_MI355X_TRACE_ALWAYS", "1")
+    eng = Engine(0)
+    used = 0
+    prev = None
+    for name, data in _indexed_inputs():
+        for bsid, indep in ((5, 1), (7, 1), (4, 0), (7, 0)):
+            kw = dict(bsid=bsid, indep=indep)
+            src = torch.from_numpy(data).cuda()
+            p = prefs_of(kw)
+            bs = 1 << (8 + 2 * bsid)
+            nb = (src.numel() + bs - 1) // bs
+            frame = torch.empty(eng.frame_bound(src.numel(), p), dtype=torch.uint8, device="cuda")
+            table, index = eng.new_table(nb), eng.new_index(src.numel(), p)
+            eng.compress_async(src, frame, p, table, index)
+            r = eng.result()
+            used += int(index[:4].cpu().numpy().view(np.uint32)[0] == 0x3258494C)
+            back = torch.zeros_like(src)
+            eng.decompress_blocks_async(frame, r.size, back, table, nb, p.frameInfo, index)
+            r2 = eng.result()
+            assert r2.size == src.numel() and torch.equal(back, src), (name, kw)
+            if prev is not None and prev[0].numel() == index.numel():       # another stream's index for this frame
+                back.zero_()
+                eng.decompress_blocks_async(frame, r.size, back, table, nb, p.frameInfo, prev[0])
+                r3 = eng.result()
+                assert r3.size == src.numel() and torch.equal(back, src), (name, kw, "foreign index")
+            prev = (index,)
+    assert used >= 28
+    eng.close()
+
+
 def test_indexed_decode_survives_wrong_indexes(L):
     """A stale, foreign, truncated or corrupted index must never change the output: the decoder notices and falls back."""
     import torch
