@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, c
     if ((uint64_t)blk.seq_base + blk.nseq > desc_cap) return;
     const SeqDesc* bd0 = desc + blk.seq_base;
     const uint64_t my_pay = table[b].src_off;
+    uint32_t chain_mine = 0;
     for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < blk.nseq; i += gridDim.y * 256) {
         const SeqDesc d = bd0[i];
         const uint32_t ml = d.w & 0xFFFFFFu;
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, c
                         cb--;
                         const BlockOut pe = table[cb];
                         s0 += pe.dst_size;
-                        if (s0 < 0) { if (count_it) atomicAdd(flags + 12, 1u); break; }                      // further back than one block: leave it to the chain
+                        if (s0 < 0) { if (count_it & 1u) atomicAdd(flags + 12, 1u); break; }                      // further back than one block: leave it to the chain
                         pay = (int64_t)pe.src_off - (int64_t)my_pay;
                         if (pe.word >> 31) {                    // stored: output position == payload position
                             if ((uint64_t)s0 + ml <= pe.dst_size) { const int64_t v = pay + s0 + IX_SRC_BIAS; if (v >= 0 && v < (1 << 23)) found = (uint32_t)v; }
@@ -371,25 +372,26 @@ __global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, c
                         if (v >= 0 && v < (1 << 23)) found = (uint32_t)v;
                         break;
                     }
-                    if (key < dmj || (uint64_t)key + ml > (uint64_t)dmj + mlj) { if (count_it) atomicAdd(flags + 13, 1u); break; }                              // straddles
+                    if (key < dmj || (uint64_t)key + ml > (uint64_t)dmj + mlj) { if (count_it & 1u) atomicAdd(flags + 13, 1u); break; }                              // straddles
                     if (dj.w >> 31) {                                                                              // in a direct match (marked by the parse)
                         const int64_t v = pay + (int64_t)(fj | (((dj.w >> 24) & 0x7Fu) << 16)) + (key - dmj);      // (already biased)
                         if (v >= 0 && v < (1 << 23)) found = (uint32_t)v;
                         break;
                     }
-                    if (fj == 0 || mlj > fj) { if (count_it) atomicAdd(flags + 14, 1u); break; }                                                                // in a run-length match
-                    if (count_it && hop + 1 == IXR_HOPS) atomicAdd(flags + 15, 1u);
+                    if (fj == 0 || mlj > fj) { if (count_it & 1u) atomicAdd(flags + 14, 1u); break; }                                                                // in a run-length match
+                    if ((count_it & 1u) && hop + 1 == IXR_HOPS) atomicAdd(flags + 15, 1u);
                     s0 -= fj; hi = lo;                                                                             // in a plain match: follow it (possibly into the block before)
                 }
             }
-            if (count_it) atomicAdd(flags + (found != IX_NOT_DIRECT ? 5 : 6), 1u);
-            if (count_it && linked && found == IX_NOT_DIRECT && off > dm) atomicAdd(flags + 11, 1u);
-        } else if (count_it && ml) atomicAdd(flags + 4, 1u);
-        {                                                       // how long is the chain that stays? (one atomic per wave)
-            const uint64_t m = __ballot(ml != 0 && !(d.w >> 31) && found == IX_NOT_DIRECT);
-            if (m && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(true))) atomicAdd(flags + 10, (uint32_t)__builtin_popcountll(m));
-        }
+            if (count_it & 1u) atomicAdd(flags + (found != IX_NOT_DIRECT ? 5 : 6), 1u);
+            if ((count_it & 1u) && linked && found == IX_NOT_DIRECT && off > dm) atomicAdd(flags + 11, 1u);
+        } else if ((count_it & 1u) && ml) atomicAdd(flags + 4, 1u);
+        chain_mine += (ml != 0 && !(d.w >> 31) && found == IX_NOT_DIRECT) ? 1u : 0u;      // how long is the chain that stays?
         dsrc[blk.seq_base + i] = found;
+    }
+    if (count_it & 2u) {                                        // (asked for by whoever chooses between the copiers and the tracer: one atomic per wave)
+        for (int o = 32; o; o >>= 1) chain_mine += __shfl_xor(chain_mine, o);
+        if ((threadIdx.x & 63u) == 0 && chain_mine) atomicAdd(flags + 10, chain_mine);
     }
 }
 
@@ -440,6 +442,7 @@ __global__ __launch_bounds__(256) void k_build_postab(void* __restrict__ ix, con
 // workgroups of earlier regions have lower indexes, so they are running or done - the same forward-progress rule as
 // k_copy_indexed's).  Regions of one block therefore finish in order, ~5 us each; independent blocks have their regions
 // interleaved over the grid (region k of every block, then region k+1 ...) so that all blocks advance together.
+constexpr uint32_t IXT_STACK = 6;                                // set-aside ranges per thread
 constexpr uint32_t IXT_TB = 16;                                  // output bytes per thread
 constexpr uint32_t IXT_WG_BYTES = 256 * IXT_TB;
 constexpr uint32_t IXT_REGION_LOG = 12;                          // a region = a workgroup's bytes
@@ -452,6 +455,8 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ 
                                                     uint32_t linked, uint32_t block_size, uint64_t hist0, uint32_t* region_cnt, uint32_t count_it)
 {
     __shared__ uint32_t go;
+    __shared__ uint64_t stk_g[IXT_STACK][256];                          // per thread: the ranges set aside where a trace split (see below)
+    __shared__ uint32_t stk_s[IXT_STACK][256];
     if (threadIdx.x == 0) go = (res->status == ST_OK && !__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) && flags[IXT_FLAG]) ? 1u : 0u;
     __syncthreads();
     if (!go) return;
@@ -490,6 +495,18 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ 
         uint32_t got = 0, hops = 0, sq_next = 0xFFFFFFFFu, n_turns = 0, n_pieces = 0, n_fromout = 0;
         uint64_t g = gpos;                                              // (position in the frame's output)
         uint32_t span = want;
+        uint32_t stk_base = 0, stk_n = 0;
+        const uint32_t tid = threadIdx.x;
+        // A range travels together until part of it turns out to come from elsewhere (the next sequence, the end of a fold ...):
+        // the rest is set aside AT THAT DEPTH and taken up when the front part is done - the hops down to there are shared.
+        // (A few entries per thread; when they run out the oldest is dropped and those bytes start from the top again.)
+        auto shorten = [&](uint32_t left) {
+            if (left >= span) return;
+            const uint32_t at = (stk_base + stk_n) % IXT_STACK;
+            stk_g[at][tid] = g + left; stk_s[at][tid] = span - left;
+            if (stk_n == IXT_STACK) stk_base = (stk_base + 1) % IXT_STACK; else stk_n++;
+            span = left;
+        };
         while (got < want && !bad) {
             const uint8_t* origin = nullptr;
             int kind = 0;                                               // 1: in the payload, 2: in the output (earlier region or call)
@@ -500,7 +517,7 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ 
                 if (cb != cb_have) { e = table[cb]; blk = blocks[cb]; cb_have = cb; }
                 const uint32_t j = (uint32_t)(g - e.dst_off);
                 if (e.dst_off != (uint64_t)cb * block_size || j >= e.dst_size) break;
-                if (e.word >> 31) { const uint32_t left = e.dst_size - j; if (left < span) span = left; origin = frame + e.src_off + j; kind = 1; break; }
+                if (e.word >> 31) { shorten(e.dst_size - j); origin = frame + e.src_off + j; kind = 1; break; }
                 const SeqDesc* bd = desc + blk.seq_base;
                 // the sequence that holds j: the table says where to start; four descriptors at once (one latency), the last
                 // of them that begins at or before j is it - or, if j is behind its end, the search goes on next turn
@@ -519,14 +536,14 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ 
                 if (j < op) break;
                 if (j >= dm + ml) { if (sq >= last) break; sq_next = sq + 1; moved = true; break; }
                 if (j < dm) {                                          // a literal: the origin
-                    const uint32_t left = dm - j; if (left < span) span = left;
+                    shorten(dm - j);
                     origin = frame + e.src_off + (d.x & 0xFFFFFFu) + (j - op); kind = 1;
                     break;
                 }
                 const uint32_t r = j - dm;
                 const uint32_t ds = (d.w >> 31) ? f24 : dsrc[blk.seq_base + sq];
                 if (ds < (1u << 23)) {                                 // a direct match: its bytes are in the payload
-                    const uint32_t left = ml - r; if (left < span) span = left;
+                    shorten(ml - r);
                     origin = frame + e.src_off + ((int64_t)ds - (int64_t)IX_SRC_BIAS) + r; kind = 1;
                     break;
                 }
@@ -535,11 +552,11 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ 
                 uint32_t rr = r, left = ml - r;
                 if (off <= r) rr = r % off;                            // the match replicates its own output: fold
                 if (off < ml && off - rr < left) left = off - rr;      // (a folded run repeats every `off` bytes)
-                if (left < span) span = left;
+                shorten(left);
                 const uint64_t back = (uint64_t)off + (r - rr);
                 if (back > g) {                                        // before this call's output: the history (linked frames)
                     if (!linked || back - g > hist0) break;
-                    if (back - g < span) span = (uint32_t)(back - g);
+                    if (back - g < span) shorten((uint32_t)(back - g));
                     origin = dst - (back - g); kind = 2;
                     break;
                 }
@@ -552,7 +569,7 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ 
                     if (rg == ready_region || __hip_atomic_load(region_cnt + rg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= IXT_REGION) {
                         if (rg != ready_region) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); ready_region = rg; }
                         const uint32_t to_end = IXT_REGION - (uint32_t)(g & (IXT_REGION - 1));
-                        if (to_end < span) span = to_end;
+                        shorten(to_end);
                         origin = dst + g; kind = 2;
                     }
                 }
@@ -561,7 +578,9 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ 
                 if (span == 0 || (kind == 1 && (origin < frame || origin + span > frame + frame_cap))) { bad = true; break; }
                 for (uint32_t q = 0; q < span; q++) out[got + q] = origin[q];
                 got += span; n_pieces++; n_fromout += kind == 2;
-                g = gpos + got; span = want - got; hops = 0;
+                hops = 0;
+                if (stk_n) { stk_n--; const uint32_t at = (stk_base + stk_n) % IXT_STACK; g = stk_g[at][tid]; span = stk_s[at][tid]; }
+                else { g = gpos + got; span = want - got; }
             } else if (!moved || ++hops >= IXT_MAX_HOPS) bad = true;
         }
         if (count_it) { atomicAdd((unsigned long long*)(flags + 26), (unsigned long long)n_turns); atomicAdd(flags + 28, n_pieces); atomicAdd(flags + 29, n_fromout); atomicMax(flags + 30, n_turns); }

@@ -346,11 +346,17 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 uint32_t n_lanes = ix_entries_hint > n_max ? ix_entries_hint : n_max;           // (grid-stride inside: a hint is enough)
                 hipLaunchKernelGGL(k_parse_indexed, dim3((n_lanes + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap,
                                    (const BlockOut*)tbl, (const void*)d_index, n_max, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, lk, (uint64_t)j.hist0);
+                const uint64_t trace_span = (uint64_t)n_max * j.block_size;            // (the last block may be short)
+                const bool trace_can = !getenv("LZ4F_MI355X_NO_TRACE") && !getenv("LZ4F_MI355X_NO_RESOLVE") && (j.block_size & 63u) == 0;
+                // (independent blocks have block-level parallelism: with many of them the copier workgroups, a chain per block, are
+                // faster than tracing every byte ~70 hops deep; measured break-even ~64 blocks of text)
+                uint32_t gate = !trace_can ? 0u : getenv("LZ4F_MI355X_TRACE_ALWAYS") ? 2u : (j.linked || n_max <= 48) ? 1u : 0u;
+                if (gate && postab.ensure((size_t)(trace_span >> 6) * 4 + 512 + ((size_t)(trace_span >> IXT_REGION_LOG) + 4) * 4)) gate = 0;      // (no memory for the position table: the copiers do it)
                 uint32_t* dsrc = (uint32_t*)((uint8_t*)desc.p + dsrc_at);
                 if (getenv("LZ4F_MI355X_NO_RESOLVE")) dsrc = nullptr;
                 else
                     hipLaunchKernelGGL(k_resolve_direct, dim3(n_max, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u), dim3(256), 0, st, d_index, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, (const SeqDesc*)desc.p,
-                                       dsrc, (uint32_t*)seqcnt.p, iprof ? 1u : 0u, lk);
+                                       dsrc, (uint32_t*)seqcnt.p, (iprof ? 1u : 0u) | (gate ? 2u : 0u), lk);
                 if (iprof) {                                                   // developer aid: how many matches are direct
                     uint32_t c[8];
                     if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(c, seqcnt.p, 32, hipMemcpyDeviceToHost) == hipSuccess)
@@ -359,20 +365,14 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 }
                 // dense frames (text): no chain at all, every output byte traced to its literal (see k_trace_copy)
                 {
-                    const uint64_t trace_span = (uint64_t)n_max * j.block_size;            // (the last block may be short)
-                    const bool trace_on = !getenv("LZ4F_MI355X_NO_TRACE") && dsrc && (j.block_size & 63u) == 0 && !postab.ensure((size_t)(trace_span >> 6) * 4 + 512 + ((size_t)(trace_span >> IXT_REGION_LOG) + 4) * 4);
-                    // (independent blocks have block-level parallelism: with many of them the copier workgroups, a chain per block, are
-                    // faster than tracing every byte ~100 hops deep; measured break-even ~64 blocks of text)
-                    const uint32_t gate = !trace_on ? 0u : getenv("LZ4F_MI355X_TRACE_ALWAYS") ? 2u : (j.linked || n_max <= 48) ? 1u : 0u;
                     hipLaunchKernelGGL(k_dense_gate, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, gate);
                     if (gate) {
                         hipLaunchKernelGGL(k_build_postab, dim3(n_max, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u), dim3(256), 0, st, d_index, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max,
                                            (const SeqDesc*)desc.p, (uint32_t*)postab.p, (uint32_t*)seqcnt.p);
                         const uint64_t n_thr = (trace_span + IXT_TB - 1) / IXT_TB;
-                        uint32_t trace_lds = 0; if (const char* tl = getenv("LZ4F_MI355X_TRACE_LDS")) trace_lds = (uint32_t)atoi(tl);
                         uint32_t* region_cnt = (uint32_t*)((uint8_t*)postab.p + (((size_t)(trace_span >> 6) * 4 + 255) & ~(size_t)255));
                         if (hipMemsetAsync(region_cnt, 0, ((size_t)(trace_span >> IXT_REGION_LOG) + 2) * 4, st) != hipSuccess) return make_err(LZ4F_ERROR_GENERIC);
-                        hipLaunchKernelGGL(k_trace_copy, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), trace_lds, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, (const BlockOut*)tbl,
+                        hipLaunchKernelGGL(k_trace_copy, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, (const BlockOut*)tbl,
                                            (const ResultRec*)d_res, n_max, d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (const uint32_t*)postab.p, (uint32_t*)seqcnt.p,
                                            lk & 1u, (uint32_t)j.block_size, (uint64_t)j.hist0, region_cnt, iprof ? 1u : 0u);
                         if (iprof) { uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(t, (uint32_t*)seqcnt.p + 24, 32, hipMemcpyDeviceToHost) == hipSuccess && t[0]) fprintf(stderr, "traced: %llu turns for %u pieces (%u read from the output), deepest thread %u turns\n", (unsigned long long)t[2] | ((unsigned long long)t[3] << 32), t[4], t[5], t[6]); }
