@@ -596,6 +596,126 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// The same origins by POINTER DOUBLING (dense frames up to IXP_MAX_SPAN of output: 4 bytes of scratch per output byte).
+// k_trace_copy walks ~70 hops per piece because every occurrence of a phrase copies the one before.  Here every output
+// byte takes ONE hop (k_pd_init): bytes that come from the payload (literals, direct matches, stored blocks) or from an
+// earlier call's output are written at once, the others leave the output position they copy in ptr[].  Then rounds of
+// ptr[i] = ptr[ptr[i]] (k_pd_round, one launch each): a byte whose source was finished in an EARLIER round copies it (the
+// launch boundary is what makes that byte visible), otherwise it adopts its source's source - the depth halves per round.
+constexpr uint32_t IXP_DONE = 0xFFFFFFE0u;                       // ptr[i] >= IXP_DONE: finished in round ptr[i] - IXP_DONE (0 = by k_pd_init)
+constexpr uint32_t IXP_ROUNDS = 16;
+constexpr uint64_t IXP_MAX_SPAN = 1ull << 30;
+
+__global__ __launch_bounds__(256) void k_pd_init(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint8_t* dst, const BlockOut* __restrict__ table,
+                                                 const ResultRec* __restrict__ res, uint32_t n_max, void* __restrict__ ix, const SeqDesc* __restrict__ desc,
+                                                 const uint32_t* __restrict__ dsrc, const uint32_t* __restrict__ postab, uint32_t* flags,
+                                                 uint32_t linked, uint32_t block_size, uint64_t hist0, uint32_t* __restrict__ ptr, uint32_t* __restrict__ remaining)
+{
+    if (res->status != ST_OK || *flags || !flags[IXT_FLAG]) return;
+    const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    const uint64_t gpos = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * IXT_TB;
+    const uint32_t b = (uint32_t)(gpos / block_size);
+    if (b >= n) return;
+    const BlockOut e = table[b];
+    if (e.dst_off != (uint64_t)b * block_size) { atomicOr(flags, 2u); return; }            // (all blocks but the last are full: checked when the index was made)
+    const uint32_t i0 = (uint32_t)(gpos - e.dst_off);
+    if (i0 >= e.dst_size) return;
+    const uint32_t want = e.dst_size - i0 < IXT_TB ? e.dst_size - i0 : IXT_TB;
+    const IxBlock blk = ix_blocks((const void*)ix)[b];
+    const SeqDesc* bd = desc + blk.seq_base;
+    uint8_t* out = dst + gpos;
+    uint32_t* pout = ptr + gpos;
+    uint32_t got = 0, open = 0;
+    bool bad = false;
+    if (e.word >> 31) {                                                // a stored block: its payload is its output
+        for (uint32_t q = 0; q < want; q++) { out[q] = frame[e.src_off + i0 + q]; pout[q] = IXP_DONE; }
+        return;
+    }
+    if (blk.nseq == 0) { atomicOr(flags, 2u); return; }
+    const uint32_t last = blk.nseq - 1;
+    uint32_t sq = postab[(e.dst_off >> 6) + (i0 >> 6)];
+    while (got < want && !bad) {
+        const uint32_t j = i0 + got;
+        if (sq > last) { bad = true; break; }
+        SeqDesc d = bd[sq];
+        while (sq < last && j >= d.z + (d.y & 0xFFFFFFu) + (d.w & 0xFFFFFFu)) d = bd[++sq];        // (sequences are ~13 bytes on such data: a step or two)
+        const uint32_t lit = d.y & 0xFFFFFFu, ml = d.w & 0xFFFFFFu, op = d.z, dm = op + lit;
+        const uint32_t f24 = (d.x >> 24) | ((d.y >> 24) << 8) | (((d.w >> 24) & 0x7Fu) << 16);
+        if (j < op || j >= dm + ml) { bad = true; break; }
+        uint32_t span = want - got;
+        const uint8_t* origin = nullptr;
+        if (j < dm) {                                                  // a literal run
+            if (dm - j < span) span = dm - j;
+            origin = frame + e.src_off + (d.x & 0xFFFFFFu) + (j - op);
+        } else {
+            const uint32_t r = j - dm;
+            const uint32_t ds = (d.w >> 31) ? f24 : dsrc[blk.seq_base + sq];
+            if (ml - r < span) span = ml - r;
+            if (ds < (1u << 23)) origin = frame + e.src_off + ((int64_t)ds - (int64_t)IX_SRC_BIAS) + r;      // a direct match
+            else {
+                const uint32_t off = f24 & 0xFFFFu;
+                if (off == 0) { bad = true; break; }
+                uint32_t rr = r;
+                if (off <= r) rr = r % off;                            // the match replicates its own output: fold
+                if (off < ml && off - rr < span) span = off - rr;
+                const uint64_t back = (uint64_t)off + (r - rr);
+                const uint64_t g = gpos + got;
+                if (back > g) {                                        // before this call's output: the history (linked frames)
+                    if (!linked || back - g > hist0) { bad = true; break; }
+                    if (back - g < span) span = (uint32_t)(back - g);
+                    for (uint32_t q = 0; q < span; q++) { out[got + q] = (dst - (back - g))[q]; pout[got + q] = IXP_DONE; }
+                } else {
+                    if (!linked && g - back < e.dst_off) { bad = true; break; }
+                    for (uint32_t q = 0; q < span; q++) pout[got + q] = (uint32_t)(g - back) + q;
+                    open += span;
+                }
+                got += span;
+                continue;
+            }
+        }
+        if (origin < frame || origin + span > frame + frame_cap) { bad = true; break; }
+        for (uint32_t q = 0; q < span; q++) { out[got + q] = origin[q]; pout[got + q] = IXP_DONE; }
+        got += span;
+    }
+    if (bad) atomicOr(flags, 2u);
+    for (int o = 32; o; o >>= 1) open += __shfl_xor(open, o);
+    if ((threadIdx.x & 63u) == 0 && open) atomicAdd(remaining, open);
+}
+
+// one round; a thread per 4 output bytes.  remaining[r] counts the bytes still open after round r (remaining[0]: after k_pd_init)
+__global__ __launch_bounds__(256) void k_pd_round(uint8_t* dst, uint32_t* ptr, const BlockOut* __restrict__ table, const ResultRec* __restrict__ res, uint32_t n_max,
+                                                  uint32_t round, uint32_t* __restrict__ remaining, uint32_t* flags)
+{
+    if (res->status != ST_OK || *flags || !flags[IXT_FLAG] || remaining[round - 1] == 0) return;
+    const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    if (n == 0) return;
+    const uint64_t total = table[n - 1].dst_off + table[n - 1].dst_size;
+    const uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    uint32_t open = 0;
+    if (i < total) {
+        const uint4 p4 = *(const uint4*)(ptr + i);
+        const uint32_t pv[4] = {p4.x, p4.y, p4.z, p4.w};
+        for (uint32_t k = 0; k < 4 && i + k < total; k++) {
+            const uint32_t q = pv[k];
+            if (q >= IXP_DONE) continue;
+            if (q >= i + k) { atomicOr(flags, 2u); continue; }         // (sources lie in front: anything else is a corrupted descriptor)
+            const uint32_t pq = __hip_atomic_load(ptr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pq >= IXP_DONE) {
+                if (pq - IXP_DONE < round) { dst[i + k] = dst[q]; __hip_atomic_store(ptr + i + k, IXP_DONE + round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                else open++;                                           // finished in this very round: its byte is not visible yet
+            } else { __hip_atomic_store(ptr + i + k, pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); open++; }
+        }
+    }
+    for (int o = 32; o; o >>= 1) open += __shfl_xor(open, o);
+    if ((threadIdx.x & 63u) == 0 && open) atomicAdd(remaining + round, open);
+}
+
+__global__ void k_pd_verdict(uint32_t* flags, const uint32_t* __restrict__ remaining)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0 && flags[IXT_FLAG] && !*flags && remaining[IXP_ROUNDS] != 0) atomicOr(flags, 2u);      // deeper than 2^16: the generic kernels
+}
+
+// ------------------------------------------------------------------------------------------------
 // One workgroup per block: the fused decoder's copier waves (decode_fused.cuh), fed from the descriptor array instead of
 // by a parser wave.
 template <class C>

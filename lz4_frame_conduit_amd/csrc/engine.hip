@@ -331,6 +331,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 hd.total_entries <= (index_size - sizeof(IxHeader)) / sizeof(IxEntry)) {
                 if (hd.total_seqs > ix_seq_cap) ix_seq_cap = (size_t)hd.total_seqs + hd.total_seqs / 4 + 4096;      // (a quarter of slack: the next stream differs)
                 if (hd.total_entries > ix_entries_hint) ix_entries_hint = hd.total_entries + hd.total_entries / 4;
+                ix_dense_hint = (uint64_t)hd.total_seqs * 48 > (uint64_t)hd.n_blocks * j.block_size;      // (short sequences: worth the tracer's scratch, see below)
             }
             if (ix_seq_cap) {
                 const size_t dsrc_at = (ix_seq_cap + 64) * sizeof(SeqDesc);
@@ -349,8 +350,8 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 const uint64_t trace_span = (uint64_t)n_max * j.block_size;            // (the last block may be short)
                 const bool trace_can = !getenv("LZ4F_MI355X_NO_TRACE") && !getenv("LZ4F_MI355X_NO_RESOLVE") && (j.block_size & 63u) == 0;
                 // (independent blocks have block-level parallelism: with many of them the copier workgroups, a chain per block, are
-                // faster than tracing every byte ~70 hops deep; measured break-even ~64 blocks of text)
-                uint32_t gate = !trace_can ? 0u : getenv("LZ4F_MI355X_TRACE_ALWAYS") ? 2u : (j.linked || n_max <= 48) ? 1u : 0u;
+                // faster than the tracers' 2.7 GiB/s; measured break-even ~100 blocks of text)
+                uint32_t gate = !trace_can ? 0u : getenv("LZ4F_MI355X_TRACE_ALWAYS") ? 2u : (j.linked || n_max <= 96) ? 1u : 0u;
                 if (gate && postab.ensure((size_t)(trace_span >> 6) * 4 + 512 + ((size_t)(trace_span >> IXT_REGION_LOG) + 4) * 4)) gate = 0;      // (no memory for the position table: the copiers do it)
                 uint32_t* dsrc = (uint32_t*)((uint8_t*)desc.p + dsrc_at);
                 if (getenv("LZ4F_MI355X_NO_RESOLVE")) dsrc = nullptr;
@@ -370,12 +371,28 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                         hipLaunchKernelGGL(k_build_postab, dim3(n_max, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u), dim3(256), 0, st, d_index, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max,
                                            (const SeqDesc*)desc.p, (uint32_t*)postab.p, (uint32_t*)seqcnt.p);
                         const uint64_t n_thr = (trace_span + IXT_TB - 1) / IXT_TB;
+                        // up to 1 GiB of output, and if the last index seen here was of a dense stream (the device decides about THIS one, but the
+                        // scratch - 4 bytes per output byte - and 18 launches are the host's to spend): one hop per byte, then pointer doubling
+                        const bool doubling = (ix_dense_hint || gate == 2) && trace_span <= IXP_MAX_SPAN && !getenv("LZ4F_MI355X_NO_DOUBLING") && !pdbuf.ensure((size_t)trace_span * 4 + 256);
+                        if (doubling) {
+                            uint32_t* remaining = (uint32_t*)seqcnt.p + 32;
+                            if (hipMemsetAsync(remaining, 0, (IXP_ROUNDS + 1) * 4, st) != hipSuccess) return make_err(LZ4F_ERROR_GENERIC);
+                            hipLaunchKernelGGL(k_pd_init, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, (const BlockOut*)tbl,
+                                               (const ResultRec*)d_res, n_max, d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (const uint32_t*)postab.p, (uint32_t*)seqcnt.p,
+                                               lk & 1u, (uint32_t)j.block_size, (uint64_t)j.hist0, (uint32_t*)pdbuf.p, remaining);
+                            for (uint32_t r = 1; r <= IXP_ROUNDS; r++)
+                                hipLaunchKernelGGL(k_pd_round, dim3((uint32_t)((trace_span / 4 + 255) / 256)), dim3(256), 0, st, j.d_dst, (uint32_t*)pdbuf.p, (const BlockOut*)tbl,
+                                                   (const ResultRec*)d_res, n_max, r, remaining, (uint32_t*)seqcnt.p);
+                            hipLaunchKernelGGL(k_pd_verdict, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, (const uint32_t*)remaining);
+                            if (iprof) { uint32_t t[IXP_ROUNDS + 1]; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(t, remaining, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) { fprintf(stderr, "doubling: bytes open after each round:"); for (uint32_t r = 0; r <= IXP_ROUNDS; r++) fprintf(stderr, " %u", t[r]); fprintf(stderr, "\n"); } }
+                        } else {
                         uint32_t* region_cnt = (uint32_t*)((uint8_t*)postab.p + (((size_t)(trace_span >> 6) * 4 + 255) & ~(size_t)255));
                         if (hipMemsetAsync(region_cnt, 0, ((size_t)(trace_span >> IXT_REGION_LOG) + 2) * 4, st) != hipSuccess) return make_err(LZ4F_ERROR_GENERIC);
                         hipLaunchKernelGGL(k_trace_copy, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, (const BlockOut*)tbl,
                                            (const ResultRec*)d_res, n_max, d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (const uint32_t*)postab.p, (uint32_t*)seqcnt.p,
                                            lk & 1u, (uint32_t)j.block_size, (uint64_t)j.hist0, region_cnt, iprof ? 1u : 0u);
                         if (iprof) { uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(t, (uint32_t*)seqcnt.p + 24, 32, hipMemcpyDeviceToHost) == hipSuccess && t[0]) fprintf(stderr, "traced: %llu turns for %u pieces (%u read from the output), deepest thread %u turns\n", (unsigned long long)t[2] | ((unsigned long long)t[3] << 32), t[4], t[5], t[6]); }
+                        }
                     }
                 }
                 tick(8, true);

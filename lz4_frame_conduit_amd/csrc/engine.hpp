@@ -54,12 +54,14 @@ struct lz4f_mi355x_engine {
     bool  own_stream = false;
     lz4f::DevBuf info, recs, table, blk_bytes, res, bad;   // workspace of the block kernels
     lz4f::DevBuf selfix, selfcnt;                          // linked frames without an index: the one made here, and its per-block counts
+    lz4f::DevBuf pdbuf;                                    // dense frames by pointer doubling: a word per output byte
     lz4f::DevBuf postab;                                   // dense frames: output position / 64 -> sequence (k_build_postab)
     lz4f::DevBuf desc, seqcnt;                             // two-kernel decode: sequence descriptors, per-block counts
     lz4f::DevBuf d_in, d_out;                              // staging for the host-pointer paths
     lz4f::PinBuf h_in, h_out, h_small;
     // indexed decode: the last index header seen (copied back asynchronously) sizes the descriptor workspace of the next call
     lz4f::PinBuf h_ix; void* ix_ev = nullptr; bool ix_pending = false; size_t ix_seq_cap = 0; uint32_t ix_entries_hint = 0;
+    bool ix_dense_hint = false;                            // the last index header seen was of a stream of short sequences
     bool  timing = false;
     void* ev[20] = {nullptr};      // hipEvent_t pairs (begin,end) per timing slot
     bool  ev_used[10] = {false};

@@ -579,13 +579,17 @@ def test_indexed_decode_same_bytes_as_generic(L):
     eng.close()
 
 
-def test_traced_decode_same_bytes(L, monkeypatch):
-    """Dense frames (text) are decoded by tracing every output byte back to its literal (k_trace_copy) instead of walking the
-    chain.  Forced on here for every input and framing, history included: same bytes as the source, and a wrong index is
-    still noticed (the tracer validates what it follows and hands over to the generic kernels)."""
+@pytest.mark.parametrize("how", ["doubling", "hops"])
+def test_traced_decode_same_bytes(L, monkeypatch, how):
+    """Dense frames (text) are decoded by tracing every output byte back to its literal instead of walking the chain: by
+    pointer doubling (k_pd_init / k_pd_round, up to 1 GiB of output) or hop by hop (k_trace_copy).  Forced on here for
+    every input and framing: same bytes as the source, and a wrong index is still noticed (the tracers validate what they
+    follow and hand over to the generic kernels)."""
     import torch
     from lz4_frame_conduit_amd.device import Engine
     monkeypatch.setenv("LZ4F_MI355X_TRACE_ALWAYS", "1")
+    if how == "hops":
+        monkeypatch.setenv("LZ4F_MI355X_NO_DOUBLING", "1")
     eng = Engine(0)
     used = 0
     prev = None
