@@ -605,6 +605,7 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ 
 constexpr uint32_t IXP_DONE = 0xFFFFFFE0u;                       // ptr[i] >= IXP_DONE: finished in round ptr[i] - IXP_DONE (0 = by k_pd_init)
 constexpr uint32_t IXP_ROUNDS = 16;
 constexpr uint64_t IXP_MAX_SPAN = 1ull << 30;
+constexpr uint32_t IXP_STRIPES = 64;                             // the count of open bytes per round is kept in 64 words (a quarter of a million waves adding to one word take 3 ms)
 
 __global__ __launch_bounds__(256) void k_pd_init(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint8_t* dst, const BlockOut* __restrict__ table,
                                                  const ResultRec* __restrict__ res, uint32_t n_max, void* __restrict__ ix, const SeqDesc* __restrict__ desc,
@@ -679,40 +680,52 @@ __global__ __launch_bounds__(256) void k_pd_init(const uint8_t* __restrict__ fra
     }
     if (bad) atomicOr(flags, 2u);
     for (int o = 32; o; o >>= 1) open += __shfl_xor(open, o);
-    if ((threadIdx.x & 63u) == 0 && open) atomicAdd(remaining, open);
+    if ((threadIdx.x & 63u) == 0 && open) atomicAdd(remaining + ((blockIdx.x * 4 + (threadIdx.x >> 6)) % IXP_STRIPES), open);
 }
 
-// one round; a thread per 4 output bytes.  remaining[r] counts the bytes still open after round r (remaining[0]: after k_pd_init)
+// one round; 4 output bytes per thread.  remaining[r][stripe] count the bytes still open after round r (r = 0: after k_pd_init)
 __global__ __launch_bounds__(256) void k_pd_round(uint8_t* dst, uint32_t* ptr, const BlockOut* __restrict__ table, const ResultRec* __restrict__ res, uint32_t n_max,
                                                   uint32_t round, uint32_t* __restrict__ remaining, uint32_t* flags)
 {
-    if (res->status != ST_OK || *flags || !flags[IXT_FLAG] || remaining[round - 1] == 0) return;
+    if (res->status != ST_OK || *flags || !flags[IXT_FLAG]) return;
+    if (__ballot(remaining[(round - 1) * IXP_STRIPES + (threadIdx.x & 63u)] != 0) == 0) return;      // nothing was open after the round before
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
     if (n == 0) return;
     const uint64_t total = table[n - 1].dst_off + table[n - 1].dst_size;
-    const uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    // a wave takes 256 consecutive bytes, 64 at a time: neighbouring lanes hold neighbouring bytes, whose sources are mostly
+    // neighbours too (one sector); the four passes are staged so that their scattered loads are in flight together
+    const uint64_t base = ((uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u)) * 4 + (threadIdx.x & 63u);
     uint32_t open = 0;
-    if (i < total) {
-        const uint4 p4 = *(const uint4*)(ptr + i);
-        const uint32_t pv[4] = {p4.x, p4.y, p4.z, p4.w};
-        for (uint32_t k = 0; k < 4 && i + k < total; k++) {
-            const uint32_t q = pv[k];
-            if (q >= IXP_DONE) continue;
-            if (q >= i + k) { atomicOr(flags, 2u); continue; }         // (sources lie in front: anything else is a corrupted descriptor)
-            const uint32_t pq = __hip_atomic_load(ptr + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (pq >= IXP_DONE) {
-                if (pq - IXP_DONE < round) { dst[i + k] = dst[q]; __hip_atomic_store(ptr + i + k, IXP_DONE + round, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-                else open++;                                           // finished in this very round: its byte is not visible yet
-            } else { __hip_atomic_store(ptr + i + k, pq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); open++; }
+    uint32_t q[4], pq[4];
+    uint8_t by[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) { const uint64_t i = base + k * 64; q[k] = i < total ? ptr[i] : IXP_DONE; }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        pq[k] = IXP_DONE + round;
+        if (q[k] < IXP_DONE) {
+            if (q[k] >= base + k * 64) { atomicOr(flags, 2u); q[k] = IXP_DONE; }      // (sources lie in front: anything else is a corrupted descriptor)
+            else pq[k] = ptr[q[k]];      // (any value this word has held is a valid answer: an older pointer only costs a round)
         }
     }
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) by[k] = (q[k] < IXP_DONE && pq[k] >= IXP_DONE && pq[k] - IXP_DONE < round) ? dst[q[k]] : (uint8_t)0;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; k++) {
+        if (q[k] >= IXP_DONE) continue;
+        const uint64_t i = base + k * 64;
+        if (pq[k] >= IXP_DONE) {
+            if (pq[k] - IXP_DONE < round) { dst[i] = by[k]; ptr[i] = IXP_DONE + round; }
+            else open++;                                               // finished in this very round: its byte is not visible yet
+        } else { ptr[i] = pq[k]; open++; }
+    }
     for (int o = 32; o; o >>= 1) open += __shfl_xor(open, o);
-    if ((threadIdx.x & 63u) == 0 && open) atomicAdd(remaining + round, open);
+    if ((threadIdx.x & 63u) == 0 && open) atomicAdd(remaining + round * IXP_STRIPES + ((blockIdx.x * 4 + (threadIdx.x >> 6)) % IXP_STRIPES), open);
 }
 
 __global__ void k_pd_verdict(uint32_t* flags, const uint32_t* __restrict__ remaining)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0 && flags[IXT_FLAG] && !*flags && remaining[IXP_ROUNDS] != 0) atomicOr(flags, 2u);      // deeper than 2^16: the generic kernels
+    if (blockIdx.x == 0 && threadIdx.x < IXP_STRIPES && flags[IXT_FLAG] && !*flags && remaining[IXP_ROUNDS * IXP_STRIPES + threadIdx.x] != 0) atomicOr(flags, 2u);      // deeper than 2^16: the generic kernels
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -373,10 +373,10 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                         const uint64_t n_thr = (trace_span + IXT_TB - 1) / IXT_TB;
                         // up to 1 GiB of output, and if the last index seen here was of a dense stream (the device decides about THIS one, but the
                         // scratch - 4 bytes per output byte - and 18 launches are the host's to spend): one hop per byte, then pointer doubling
-                        const bool doubling = (ix_dense_hint || gate == 2) && trace_span <= IXP_MAX_SPAN && !getenv("LZ4F_MI355X_NO_DOUBLING") && !pdbuf.ensure((size_t)trace_span * 4 + 256);
+                        const bool doubling = (ix_dense_hint || gate == 2) && trace_span <= IXP_MAX_SPAN && !getenv("LZ4F_MI355X_NO_DOUBLING") && !pdbuf.ensure((size_t)trace_span * 4 + 256 + (IXP_ROUNDS + 1) * IXP_STRIPES * 4);
                         if (doubling) {
-                            uint32_t* remaining = (uint32_t*)seqcnt.p + 32;
-                            if (hipMemsetAsync(remaining, 0, (IXP_ROUNDS + 1) * 4, st) != hipSuccess) return make_err(LZ4F_ERROR_GENERIC);
+                            uint32_t* remaining = (uint32_t*)((uint8_t*)pdbuf.p + (((size_t)trace_span * 4 + 255) & ~(size_t)255));
+                            if (hipMemsetAsync(remaining, 0, (IXP_ROUNDS + 1) * IXP_STRIPES * 4, st) != hipSuccess) return make_err(LZ4F_ERROR_GENERIC);
                             hipLaunchKernelGGL(k_pd_init, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, (const BlockOut*)tbl,
                                                (const ResultRec*)d_res, n_max, d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (const uint32_t*)postab.p, (uint32_t*)seqcnt.p,
                                                lk & 1u, (uint32_t)j.block_size, (uint64_t)j.hist0, (uint32_t*)pdbuf.p, remaining);
@@ -384,7 +384,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                                 hipLaunchKernelGGL(k_pd_round, dim3((uint32_t)((trace_span / 4 + 255) / 256)), dim3(256), 0, st, j.d_dst, (uint32_t*)pdbuf.p, (const BlockOut*)tbl,
                                                    (const ResultRec*)d_res, n_max, r, remaining, (uint32_t*)seqcnt.p);
                             hipLaunchKernelGGL(k_pd_verdict, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, (const uint32_t*)remaining);
-                            if (iprof) { uint32_t t[IXP_ROUNDS + 1]; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(t, remaining, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) { fprintf(stderr, "doubling: bytes open after each round:"); for (uint32_t r = 0; r <= IXP_ROUNDS; r++) fprintf(stderr, " %u", t[r]); fprintf(stderr, "\n"); } }
+                            if (iprof) { static uint32_t t[(IXP_ROUNDS + 1) * IXP_STRIPES]; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(t, remaining, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) { fprintf(stderr, "doubling: bytes open after each round:"); for (uint32_t r = 0; r <= IXP_ROUNDS; r++) { uint64_t sum = 0; for (uint32_t q = 0; q < IXP_STRIPES; q++) sum += t[r * IXP_STRIPES + q]; fprintf(stderr, " %llu", (unsigned long long)sum); } fprintf(stderr, "\n"); } }
                         } else {
                         uint32_t* region_cnt = (uint32_t*)((uint8_t*)postab.p + (((size_t)(trace_span >> 6) * 4 + 255) & ~(size_t)255));
                         if (hipMemsetAsync(region_cnt, 0, ((size_t)(trace_span >> IXT_REGION_LOG) + 2) * 4, st) != hipSuccess) return make_err(LZ4F_ERROR_GENERIC);

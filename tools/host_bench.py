@@ -8,7 +8,12 @@ from lz4_frame_conduit_amd import _ffi, conduit, datagen
 n = (int(sys.argv[1]) if len(sys.argv) > 1 else 1024) << 20
 bsid = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 L = _ffi.lib()
-src = np.ascontiguousarray(datagen.synth50(n, 1234))
+kind = os.environ.get('DATA', 'synth50')          # DATA=text: dense data (13-byte sequences)
+if kind == 'text':
+    t = datagen.synth_text(min(n, 64 << 20), 99)
+    src = np.ascontiguousarray(np.tile(t, max(1, n // t.size)))
+else:
+    src = np.ascontiguousarray(datagen.synth50(n, 1234))
 prefs = conduit.make_preferences(blockSizeID=bsid, blockMode=0 if os.environ.get('LINKED') else 1)
 bound = L.lz4f_mi355x_compressFrameBound(n, ctypes.byref(prefs))
 dst = np.empty(bound, dtype=np.uint8); back = np.empty(n + 8, dtype=np.uint8)
@@ -28,5 +33,5 @@ for it in range(4):
     if it: best_c = min(best_c, t1 - t0); best_d = min(best_d, t3 - t2)
 ok = r2 == n and bool(np.array_equal(back[:n], src))
 g = n / 2**30
-print({"MiB": n >> 20, "block": 1 << (8 + 2 * bsid), "ok": ok, "ratio": round(n / csize, 4),
+print({"data": kind, "MiB": n >> 20, "block": 1 << (8 + 2 * bsid), "ok": ok, "ratio": round(n / csize, 4),
        "compress_GiBs": round(g / best_c, 2), "decompress_GiBs": round(g / best_d, 2), "e2e_GiBs": round(g / (best_c + best_d), 2)})
