@@ -596,15 +596,17 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same origins by POINTER DOUBLING (dense frames up to IXP_MAX_SPAN of output: 4 bytes of scratch per output byte).
+// The same origins by POINTER DOUBLING (4 bytes of scratch per output byte: 16 GiB for a 4 GiB frame, of the 288 there are;
+// if that cannot be had, k_trace_copy does it).
 // k_trace_copy walks ~70 hops per piece because every occurrence of a phrase copies the one before.  Here every output
 // byte takes ONE hop (k_pd_init): bytes that come from the payload (literals, direct matches, stored blocks) or from an
 // earlier call's output are written at once, the others leave the output position they copy in ptr[].  Then rounds of
 // ptr[i] = ptr[ptr[i]] (k_pd_round, one launch each): a byte whose source was finished in an EARLIER round copies it (the
 // launch boundary is what makes that byte visible), otherwise it adopts its source's source - the depth halves per round.
 constexpr uint32_t IXP_DONE = 0xFFFFFFE0u;                       // ptr[i] >= IXP_DONE: finished in round ptr[i] - IXP_DONE (0 = by k_pd_init)
-constexpr uint32_t IXP_ROUNDS = 16;
-constexpr uint64_t IXP_MAX_SPAN = 1ull << 30;
+constexpr uint32_t IXP_ROUNDS = 12;
+constexpr uint32_t IXP_JUMPS = 8;                                // steps along the trail per round
+constexpr uint64_t IXP_MAX_SPAN = 0xFFF00000ull;                 // (positions are 32-bit words below IXP_DONE)
 constexpr uint32_t IXP_STRIPES = 64;                             // the count of open bytes per round is kept in 64 words (a quarter of a million waves adding to one word take 3 ms)
 
 __global__ __launch_bounds__(256) void k_pd_init(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint8_t* dst, const BlockOut* __restrict__ table,
@@ -696,28 +698,38 @@ __global__ __launch_bounds__(256) void k_pd_round(uint8_t* dst, uint32_t* ptr, c
     // neighbours too (one sector); the four passes are staged so that their scattered loads are in flight together
     const uint64_t base = ((uint64_t)blockIdx.x * 256 + (threadIdx.x & ~63u)) * 4 + (threadIdx.x & 63u);
     uint32_t open = 0;
-    uint32_t q[4], pq[4];
+    uint32_t cur[4];                                                  // where byte k's trail stands
+    uint32_t st[4];                                                   // 0: already finished / not mine, 1: open, 2: cur is a finished byte to copy
     uint8_t by[4];
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) { const uint64_t i = base + k * 64; q[k] = i < total ? ptr[i] : IXP_DONE; }
-#pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
-        pq[k] = IXP_DONE + round;
-        if (q[k] < IXP_DONE) {
-            if (q[k] >= base + k * 64) { atomicOr(flags, 2u); q[k] = IXP_DONE; }      // (sources lie in front: anything else is a corrupted descriptor)
-            else pq[k] = ptr[q[k]];      // (any value this word has held is a valid answer: an older pointer only costs a round)
+        const uint64_t i = base + k * 64;
+        cur[k] = i < total ? ptr[i] : IXP_DONE;
+        st[k] = cur[k] < IXP_DONE ? 1u : 0u;
+        if (st[k] && cur[k] >= i) { atomicOr(flags, 2u); st[k] = 0; }  // (sources lie in front: anything else is a corrupted descriptor)
+    }
+    // IXP_JUMPS steps along the trail per round (each word read may already be this round's: any value it has held is valid)
+#pragma unroll
+    for (uint32_t jump = 0; jump < IXP_JUMPS; jump++) {
+        uint32_t v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) v[k] = st[k] == 1u ? ptr[cur[k]] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            if (st[k] != 1u) continue;
+            if (v[k] >= IXP_DONE) { st[k] = (v[k] - IXP_DONE < round) ? 2u : 3u; }      // finished earlier: copy it; in this very round: not visible yet, wait here
+            else if (v[k] >= cur[k]) { atomicOr(flags, 2u); st[k] = 0; }
+            else cur[k] = v[k];
         }
     }
 #pragma unroll
-    for (uint32_t k = 0; k < 4; k++) by[k] = (q[k] < IXP_DONE && pq[k] >= IXP_DONE && pq[k] - IXP_DONE < round) ? dst[q[k]] : (uint8_t)0;
+    for (uint32_t k = 0; k < 4; k++) by[k] = st[k] == 2u ? dst[cur[k]] : (uint8_t)0;
 #pragma unroll
     for (uint32_t k = 0; k < 4; k++) {
-        if (q[k] >= IXP_DONE) continue;
+        if (st[k] == 0u) continue;
         const uint64_t i = base + k * 64;
-        if (pq[k] >= IXP_DONE) {
-            if (pq[k] - IXP_DONE < round) { dst[i] = by[k]; ptr[i] = IXP_DONE + round; }
-            else open++;                                               // finished in this very round: its byte is not visible yet
-        } else { ptr[i] = pq[k]; open++; }
+        if (st[k] == 2u) { dst[i] = by[k]; ptr[i] = IXP_DONE + round; }
+        else { ptr[i] = cur[k]; open++; }
     }
     for (int o = 32; o; o >>= 1) open += __shfl_xor(open, o);
     if ((threadIdx.x & 63u) == 0 && open) atomicAdd(remaining + round * IXP_STRIPES + ((blockIdx.x * 4 + (threadIdx.x >> 6)) % IXP_STRIPES), open);

@@ -349,9 +349,10 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                                    (const BlockOut*)tbl, (const void*)d_index, n_max, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, lk, (uint64_t)j.hist0);
                 const uint64_t trace_span = (uint64_t)n_max * j.block_size;            // (the last block may be short)
                 const bool trace_can = !getenv("LZ4F_MI355X_NO_TRACE") && !getenv("LZ4F_MI355X_NO_RESOLVE") && (j.block_size & 63u) == 0;
-                // (independent blocks have block-level parallelism: with many of them the copier workgroups, a chain per block, are
-                // faster than the tracers' 2.7 GiB/s; measured break-even ~100 blocks of text)
-                uint32_t gate = !trace_can ? 0u : getenv("LZ4F_MI355X_TRACE_ALWAYS") ? 2u : (j.linked || n_max <= 96) ? 1u : 0u;
+                // (pointer doubling does ~12 GiB/s on text whatever the framing; hop by hop it is 1.3 GiB/s, which only pays where
+                // there is no block-level parallelism - linked frames; independent blocks then stay with the copier workgroups, 4.8 GiB/s)
+                const bool can_double = (ix_dense_hint || getenv("LZ4F_MI355X_TRACE_ALWAYS")) && trace_span <= IXP_MAX_SPAN && !getenv("LZ4F_MI355X_NO_DOUBLING");
+                uint32_t gate = !trace_can ? 0u : getenv("LZ4F_MI355X_TRACE_ALWAYS") ? 2u : (j.linked || can_double) ? 1u : 0u;
                 if (gate && postab.ensure((size_t)(trace_span >> 6) * 4 + 512 + ((size_t)(trace_span >> IXT_REGION_LOG) + 4) * 4)) gate = 0;      // (no memory for the position table: the copiers do it)
                 uint32_t* dsrc = (uint32_t*)((uint8_t*)desc.p + dsrc_at);
                 if (getenv("LZ4F_MI355X_NO_RESOLVE")) dsrc = nullptr;
@@ -371,9 +372,9 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                         hipLaunchKernelGGL(k_build_postab, dim3(n_max, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u), dim3(256), 0, st, d_index, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max,
                                            (const SeqDesc*)desc.p, (uint32_t*)postab.p, (uint32_t*)seqcnt.p);
                         const uint64_t n_thr = (trace_span + IXT_TB - 1) / IXT_TB;
-                        // up to 1 GiB of output, and if the last index seen here was of a dense stream (the device decides about THIS one, but the
+                        // if the last index seen here was of a dense stream (the device decides about THIS one, but the
                         // scratch - 4 bytes per output byte - and 18 launches are the host's to spend): one hop per byte, then pointer doubling
-                        const bool doubling = (ix_dense_hint || gate == 2) && trace_span <= IXP_MAX_SPAN && !getenv("LZ4F_MI355X_NO_DOUBLING") && !pdbuf.ensure((size_t)trace_span * 4 + 256 + (IXP_ROUNDS + 1) * IXP_STRIPES * 4);
+                        const bool doubling = can_double && !pdbuf.ensure((size_t)trace_span * 4 + 256 + (IXP_ROUNDS + 1) * IXP_STRIPES * 4);
                         if (doubling) {
                             uint32_t* remaining = (uint32_t*)((uint8_t*)pdbuf.p + (((size_t)trace_span * 4 + 255) & ~(size_t)255));
                             if (hipMemsetAsync(remaining, 0, (IXP_ROUNDS + 1) * IXP_STRIPES * 4, st) != hipSuccess) return make_err(LZ4F_ERROR_GENERIC);
