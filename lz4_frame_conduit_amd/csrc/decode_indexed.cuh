@@ -315,11 +315,12 @@ constexpr uint32_t IX_NOT_DIRECT = 0xFFFFFFFFu;
 // In a linked frame the source may start in the block before (offsets reach 64 KiB back): the search then runs over that
 // block's descriptors - or, if that block is stored, its payload IS its output.  The answer is the payload position
 // relative to the asking block's payload (negative for the block before) + IX_SRC_BIAS.
+constexpr uint32_t IXT_FLAG = 24;                               // flags[IXT_FLAG] != 0: a dense frame, decoded by the tracers below (2: decided before k_resolve_direct, which was skipped)
 __global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, const BlockOut* __restrict__ table, const ResultRec* __restrict__ res,
                                                         uint32_t n_max, const SeqDesc* __restrict__ desc, uint32_t* __restrict__ dsrc,
                                                         uint32_t* __restrict__ flags, uint32_t count_it, uint32_t linked)
 {
-    if (res->status != ST_OK || *flags) return;
+    if (res->status != ST_OK || *flags || flags[IXT_FLAG]) return;      // (dense by the early gate: nobody will ask for the resolved sources)
     const uint64_t desc_cap = flags[9];
     const uint32_t b = blockIdx.x;                             // (gridDim.y workgroups per block)
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
@@ -406,11 +407,24 @@ __global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, c
 //                     search), and the check that the descriptors tile the block's output
 //   k_trace_copy      the gathers
 constexpr uint32_t IXT_MAX_HOPS = 4096;                         // then the frame goes to the generic kernels
-constexpr uint32_t IXT_FLAG = 24;                               // flags[IXT_FLAG] != 0: dense, traced
 
-__global__ void k_dense_gate(uint32_t* __restrict__ flags, uint32_t on)
+// early != 0: before k_resolve_direct, from the sequence density alone (under 20 output bytes per sequence: text) - such a
+// frame goes to the doubling kernels, which do not need the resolved sources, so k_resolve_direct is skipped (flag value 2)
+__global__ void k_dense_gate(uint32_t* __restrict__ flags, uint32_t on, const BlockOut* __restrict__ table, const ResultRec* __restrict__ res, uint32_t n_max, uint32_t early)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) flags[IXT_FLAG] = (on && !*flags && (on > 1 || (uint64_t)flags[10] * 2 > flags[9])) ? 1u : 0u;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (early) {
+        uint32_t v = 0;
+        if (on && !*flags && res->status == ST_OK) {
+            const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+            const uint64_t total = n ? table[n - 1].dst_off + table[n - 1].dst_size : 0;
+            if ((uint64_t)flags[9] * 20 > total) v = 2u;
+        }
+        flags[IXT_FLAG] = v;
+        return;
+    }
+    if (flags[IXT_FLAG]) return;
+    flags[IXT_FLAG] = (on && !*flags && (on > 1 || (uint64_t)flags[10] * 2 > flags[9])) ? 1u : 0u;
 }
 
 __global__ __launch_bounds__(256) void k_build_postab(void* __restrict__ ix, const BlockOut* __restrict__ table, const ResultRec* __restrict__ res, uint32_t n_max,
@@ -469,6 +483,7 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ 
         const uint32_t k = blockIdx.x / per_k, rem = blockIdx.x % per_k;
         wg_pos = (uint64_t)(rem / (IXT_REGION / IXT_WG_BYTES)) * block_size + (uint64_t)k * IXT_REGION + (uint64_t)(rem % (IXT_REGION / IXT_WG_BYTES)) * IXT_WG_BYTES;
     }
+    const bool have_dsrc = flags[IXT_FLAG] != 2u;                      // (2: k_resolve_direct was skipped)
     const uint64_t gpos = wg_pos + threadIdx.x * IXT_TB;
     const uint32_t my_region = (uint32_t)(wg_pos >> IXT_REGION_LOG);
     const uint32_t b = (uint32_t)(wg_pos / block_size);
@@ -541,7 +556,7 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ 
                     break;
                 }
                 const uint32_t r = j - dm;
-                const uint32_t ds = (d.w >> 31) ? f24 : dsrc[blk.seq_base + sq];
+                const uint32_t ds = (d.w >> 31) ? f24 : (have_dsrc ? dsrc[blk.seq_base + sq] : IX_NOT_DIRECT);
                 if (ds < (1u << 23)) {                                 // a direct match: its bytes are in the payload
                     shorten(ml - r);
                     origin = frame + e.src_off + ((int64_t)ds - (int64_t)IX_SRC_BIAS) + r; kind = 1;
@@ -616,6 +631,7 @@ __global__ __launch_bounds__(256) void k_pd_init(const uint8_t* __restrict__ fra
 {
     if (res->status != ST_OK || *flags || !flags[IXT_FLAG]) return;
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    const bool have_dsrc = flags[IXT_FLAG] != 2u;                      // (2: k_resolve_direct was skipped)
     const uint64_t gpos = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * IXT_TB;
     const uint32_t b = (uint32_t)(gpos / block_size);
     if (b >= n) return;
@@ -652,7 +668,7 @@ __global__ __launch_bounds__(256) void k_pd_init(const uint8_t* __restrict__ fra
             origin = frame + e.src_off + (d.x & 0xFFFFFFu) + (j - op);
         } else {
             const uint32_t r = j - dm;
-            const uint32_t ds = (d.w >> 31) ? f24 : dsrc[blk.seq_base + sq];
+            const uint32_t ds = (d.w >> 31) ? f24 : (have_dsrc ? dsrc[blk.seq_base + sq] : IX_NOT_DIRECT);
             if (ml - r < span) span = ml - r;
             if (ds < (1u << 23)) origin = frame + e.src_off + ((int64_t)ds - (int64_t)IX_SRC_BIAS) + r;      // a direct match
             else {

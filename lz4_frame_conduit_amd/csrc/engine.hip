@@ -336,7 +336,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             if (ix_seq_cap) {
                 const size_t dsrc_at = (ix_seq_cap + 64) * sizeof(SeqDesc);
                 if (desc.ensure(dsrc_at + (ix_seq_cap + 64) * 4) || seqcnt.ensure(256 + (size_t)n_max * (8 + 8 * IXL_PUB))) return make_err(LZ4F_ERROR_allocation_failed);
-                HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 64 + (j.linked ? 192 + (size_t)n_max * 8 : 0), st));      // flags (+ per block of a linked frame: the "done" word and the count of published ranges)
+                HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 128 + (j.linked ? 128 + (size_t)n_max * 8 : 0), st));      // flags (+ per block of a linked frame: the "done" word and the count of published ranges)
                 uint32_t* done = (uint32_t*)seqcnt.p + 64;
                 uint32_t lk = j.linked ? 1u : 0u;                                  // (bits 1..: chain gate, see k_copy_indexed)
                 if (j.linked) if (const char* gs = getenv("LZ4F_MI355X_CHAIN_GATE")) { const int gv = atoi(gs); if (gv > 0 && gv < (1 << 20)) lk |= (uint32_t)gv << 1; }
@@ -354,6 +354,8 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 const bool can_double = (ix_dense_hint || getenv("LZ4F_MI355X_TRACE_ALWAYS")) && trace_span <= IXP_MAX_SPAN && !getenv("LZ4F_MI355X_NO_DOUBLING");
                 uint32_t gate = !trace_can ? 0u : getenv("LZ4F_MI355X_TRACE_ALWAYS") ? 2u : (j.linked || can_double) ? 1u : 0u;
                 if (gate && postab.ensure((size_t)(trace_span >> 6) * 4 + 512 + ((size_t)(trace_span >> IXT_REGION_LOG) + 4) * 4)) gate = 0;      // (no memory for the position table: the copiers do it)
+                if (gate && can_double)                                        // (dense by the sequence density: no need to resolve anything)
+                    hipLaunchKernelGGL(k_dense_gate, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, gate, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, 1u);
                 uint32_t* dsrc = (uint32_t*)((uint8_t*)desc.p + dsrc_at);
                 if (getenv("LZ4F_MI355X_NO_RESOLVE")) dsrc = nullptr;
                 else
@@ -367,7 +369,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 }
                 // dense frames (text): no chain at all, every output byte traced to its literal (see k_trace_copy)
                 {
-                    hipLaunchKernelGGL(k_dense_gate, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, gate);
+                    hipLaunchKernelGGL(k_dense_gate, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, gate, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, 0u);
                     if (gate) {
                         hipLaunchKernelGGL(k_build_postab, dim3(n_max, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u), dim3(256), 0, st, d_index, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max,
                                            (const SeqDesc*)desc.p, (uint32_t*)postab.p, (uint32_t*)seqcnt.p);
