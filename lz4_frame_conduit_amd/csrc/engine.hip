@@ -274,7 +274,18 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         bool indexed = false;
         void* d_index = j.d_index; size_t index_size = j.index_size;
         bool self_indexed = false;
-        if (mode == 'f' && j.linked && !j.d_index && j.hist0 <= 65536 && n_max >= 2 && !getenv("LZ4F_MI355X_NO_INDEX") && !getenv("LZ4F_MI355X_NO_SELFINDEX")) {
+        // A linked frame is one match chain without a usable index (seconds instead of milliseconds on dense data), so for
+        // those the header of the index that came along is read NOW (a host synchronisation, ~30 us): the compressor marks an
+        // index unusable when the stream had more sequences than it had room for, and then one is made here instead.
+        IxHeader hd_now; memset(&hd_now, 0, sizeof(hd_now));
+        bool have_now = false;
+        if (mode == 'f' && j.linked && j.d_index && j.index_size >= sizeof(IxHeader) && !getenv("LZ4F_MI355X_NO_INDEX")) {
+            HIP_TRY(hipMemcpyAsync(&hd_now, j.d_index, sizeof(hd_now), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            have_now = true;
+            if (hd_now.magic != IX_MAGIC || hd_now.stride != IX_STRIDE) { d_index = nullptr; index_size = 0; have_now = false; }
+        }
+        if (mode == 'f' && j.linked && !d_index && j.hist0 <= 65536 && n_max >= 2 && !getenv("LZ4F_MI355X_NO_INDEX") && !getenv("LZ4F_MI355X_NO_SELFINDEX")) {
             // A linked frame without an index (a foreign one: the reference's default output): make the index here - a lane per block
             // walks the payload (parsing needs no history), a scan places the blocks - and take the same kernels as with the
             // compressor's index.  Two host synchronisations (the totals size the buffers); anything odd leaves the frame to the
@@ -327,6 +338,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 HIP_TRY(hipStreamSynchronize(st));
                 have = true;
             }
+            if (have_now && !self_indexed) { hd = hd_now; have = true; }          // (linked frames: this very index's header, read above)
             if (have && hd.magic == IX_MAGIC && hd.stride == IX_STRIDE && hd.total_seqs <= (uint64_t)hd.total_entries * (IX_STRIDE + 1) &&
                 hd.total_entries <= (index_size - sizeof(IxHeader)) / sizeof(IxEntry)) {
                 if (hd.total_seqs > ix_seq_cap) ix_seq_cap = (size_t)hd.total_seqs + hd.total_seqs / 4 + 4096;      // (a quarter of slack: the next stream differs)
