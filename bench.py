@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--block-checksum", type=int, default=0)
     ap.add_argument("--linked", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the side legs (other framings, dense data): what the rocprofv3 summaries under profiles/ are taken with, so that their per-kernel averages are the headline launches' only")
     ap.add_argument("--no-index", action="store_true", help="decode without the compressor's sequence index (what a foreign frame gets)")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
     args = ap.parse_args()
@@ -167,7 +168,7 @@ def main():
     r2 = eng.result()
     ok = bool(r2.size == n and torch.equal(back, src))
     generic_ms = None
-    if index is not None and rank == 0:                       # the same frame through the generic decoder (no index), outside the timed region
+    if index is not None and rank == 0 and not args.headline_only:      # the same frame through the generic decoder (no index), outside the timed region
         t = []
         for _ in range(3):
             back.zero_()
@@ -178,7 +179,7 @@ def main():
         generic_ms = round(min(t), 4)
 
     linked_leg = dense_leg = None
-    if rank == 0 and world == 1 and not args.linked and n >= (1 << 30):
+    if rank == 0 and world == 1 and not args.linked and n >= (1 << 30) and not args.headline_only:
         # the reference's DEFAULT framing (64 KiB linked blocks), outside the timed region: 1 GiB of the same stream, with the index
         try:
             m = 1 << 30
