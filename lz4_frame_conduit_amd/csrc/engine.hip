@@ -317,6 +317,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 self_indexed = true;
                 if (ix_seq_cap < (size_t)tot[9] + 4096) ix_seq_cap = (size_t)tot[9] + 4096;
                 if (ix_entries_hint < tot[8]) ix_entries_hint = tot[8];
+                ix_dense_hint = (uint64_t)tot[9] * 48 > (uint64_t)n_max * j.block_size;      // (this very frame's density: see the doubling scratch below)
             }
         }
         // (linked frames: only with a table that has every block's output position - the compressor's, or the one just made)

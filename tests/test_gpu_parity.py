@@ -619,6 +619,34 @@ def test_traced_decode_same_bytes(L, monkeypatch, how):
     eng.close()
 
 
+def test_linked_dense_frame_with_unusable_index(L):
+    """Text has more sequences than an index of the recommended size has room for: the compressor marks it unusable.  For a
+    linked frame that must not mean the window kernel (one chain, ~50 ms per MiB): the decoder makes its own index and
+    decodes by pointer doubling.  Same bytes, and in a time the chain could not do."""
+    import torch
+    from lz4_frame_conduit_amd.device import Engine
+    eng = Engine(0)
+    eng.set_timing(True)
+    data = np.tile(datagen.synth_text(4 << 20, 5), 4)
+    src = torch.from_numpy(data).cuda()
+    p = prefs_of(dict(bsid=4, indep=0))
+    nb = src.numel() >> 16
+    frame = torch.empty(eng.frame_bound(src.numel(), p), dtype=torch.uint8, device="cuda")
+    table, index = eng.new_table(nb), eng.new_index(src.numel(), p)
+    eng.compress_async(src, frame, p, table, index)
+    r = eng.result()
+    assert int(index[:4].cpu().numpy().view(np.uint32)[0]) != 0x3258494C           # unusable, as expected for this density
+    best = 1e9
+    for _ in range(3):
+        back = torch.zeros_like(src)
+        eng.decompress_blocks_async(frame, r.size, back, table, nb, p.frameInfo, index)
+        r2 = eng.result()
+        assert r2.size == src.numel() and torch.equal(back, src)
+        best = min(best, eng.get_timing()["decode"])
+    assert best < 200.0, best                                                       # (16 MiB through the window kernel: ~850 ms; here ~2)
+    eng.close()
+
+
 def test_indexed_decode_survives_wrong_indexes(L):
     """A stale, foreign, truncated or corrupted index must never change the output: the decoder notices and falls back."""
     import torch
