@@ -316,6 +316,16 @@ constexpr uint32_t IX_NOT_DIRECT = 0xFFFFFFFFu;
 // block's descriptors - or, if that block is stored, its payload IS its output.  The answer is the payload position
 // relative to the asking block's payload (negative for the block before) + IX_SRC_BIAS.
 constexpr uint32_t IXT_FLAG = 24;                               // flags[IXT_FLAG] != 0: a dense frame, decoded by the tracers below (2: decided before k_resolve_direct, which was skipped)
+constexpr uint32_t IXT_SAMPLE_ALL = 256;                         // frames of up to this many blocks count every block's first workgroup
+constexpr uint32_t IXT_CHAIN = 32;                               // flags[32..63]: matches left on the chain (striped; summed into flags[10] by the gate)
+constexpr uint32_t IXT_DECIDED = 25;                            // flags[IXT_DECIDED]: what the gate decided (kept for the host: the next call's hint)
+// a tracer gives up (too deep, or something inconsistent).  If the resolved sources exist (gate value 1) the copier workgroups
+// launched behind take the frame - they check everything themselves; otherwise the generic kernels do
+__device__ __forceinline__ void ixt_fail(uint32_t* flags)
+{
+    if (__hip_atomic_load(flags + IXT_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 2u) atomicOr(flags, 2u);
+    else __hip_atomic_store(flags + IXT_FLAG, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, const BlockOut* __restrict__ table, const ResultRec* __restrict__ res,
                                                         uint32_t n_max, const SeqDesc* __restrict__ desc, uint32_t* __restrict__ dsrc,
                                                         uint32_t* __restrict__ flags, uint32_t count_it, uint32_t linked)
@@ -390,9 +400,12 @@ __global__ __launch_bounds__(256) void k_resolve_direct(void* __restrict__ ix, c
         chain_mine += (ml != 0 && !(d.w >> 31) && found == IX_NOT_DIRECT) ? 1u : 0u;      // how long is the chain that stays?
         dsrc[blk.seq_base + i] = found;
     }
-    if (count_it & 2u) {                                        // (asked for by whoever chooses between the copiers and the tracer: one atomic per wave)
+    {                                                           // (for whoever chooses between the copiers and the tracers: one atomic per wave, over 32 striped words)
         for (int o = 32; o; o >>= 1) chain_mine += __shfl_xor(chain_mine, o);
-        if ((threadIdx.x & 63u) == 0 && chain_mine) atomicAdd(flags + 10, chain_mine);
+        // (a SAMPLE: the first of the gridDim.y workgroups of a block, of every eighth block when there are many - the gate scales it up;
+        // an atomic from every wave of the grid cost the headline 0.14 ms)
+        const bool sampled = blockIdx.y == 0 && (n <= IXT_SAMPLE_ALL || (b & 7u) == 0);
+        if (sampled && (threadIdx.x & 63u) == 0 && chain_mine) atomicAdd(flags + IXT_CHAIN + ((b * 4 + (threadIdx.x >> 6)) & 31u), chain_mine);
     }
 }
 
@@ -410,7 +423,7 @@ constexpr uint32_t IXT_MAX_HOPS = 4096;                         // then the fram
 
 // early != 0: before k_resolve_direct, from the sequence density alone (under 20 output bytes per sequence: text) - such a
 // frame goes to the doubling kernels, which do not need the resolved sources, so k_resolve_direct is skipped (flag value 2)
-__global__ void k_dense_gate(uint32_t* __restrict__ flags, uint32_t on, const BlockOut* __restrict__ table, const ResultRec* __restrict__ res, uint32_t n_max, uint32_t early)
+__global__ void k_dense_gate(uint32_t* __restrict__ flags, uint32_t on, const BlockOut* __restrict__ table, const ResultRec* __restrict__ res, uint32_t n_max, uint32_t early, uint32_t resolve_gy)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (early) {
@@ -420,11 +433,18 @@ __global__ void k_dense_gate(uint32_t* __restrict__ flags, uint32_t on, const Bl
             const uint64_t total = n ? table[n - 1].dst_off + table[n - 1].dst_size : 0;
             if ((uint64_t)flags[9] * 20 > total) v = 2u;
         }
-        flags[IXT_FLAG] = v;
+        flags[IXT_FLAG] = v; flags[IXT_DECIDED] = v;
         return;
     }
     if (flags[IXT_FLAG]) return;
-    flags[IXT_FLAG] = (on && !*flags && (on > 1 || (uint64_t)flags[10] * 2 > flags[9])) ? 1u : 0u;
+    uint64_t chain = 0;
+    for (uint32_t q = 0; q < 32; q++) chain += flags[IXT_CHAIN + q];
+    const uint32_t nb = res->n_blocks < n_max ? res->n_blocks : n_max;
+    chain *= (uint64_t)resolve_gy * (nb <= IXT_SAMPLE_ALL ? 1u : 8u);             // (k_resolve_direct counted a sample)
+    flags[10] = chain > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)chain;
+    const bool dense = !*flags && chain * 2 > flags[9];
+    flags[IXT_FLAG] = (on && !*flags && (on > 1 || dense)) ? 1u : 0u;
+    flags[IXT_DECIDED] = dense || flags[IXT_FLAG];             // (also when the tracers were not on offer this time: the host's hint for the next call)
 }
 
 __global__ __launch_bounds__(256) void k_build_postab(void* __restrict__ ix, const BlockOut* __restrict__ table, const ResultRec* __restrict__ res, uint32_t n_max,
@@ -437,7 +457,7 @@ __global__ __launch_bounds__(256) void k_build_postab(void* __restrict__ ix, con
     const BlockOut e = table[b];
     if (e.word >> 31) return;
     const IxBlock blk = ix_blocks((const void*)ix)[b];
-    if ((uint64_t)blk.seq_base + blk.nseq > flags[9] || (e.dst_off & 63u)) { atomicOr(flags, 2u); return; }
+    if ((uint64_t)blk.seq_base + blk.nseq > flags[9] || (e.dst_off & 63u)) { ixt_fail(flags); return; }
     const SeqDesc* bd = desc + blk.seq_base;
     uint32_t* T = postab + (e.dst_off >> 6);
     for (uint32_t i = blockIdx.y * 256 + threadIdx.x; i < blk.nseq; i += gridDim.y * 256) {
@@ -445,7 +465,7 @@ __global__ __launch_bounds__(256) void k_build_postab(void* __restrict__ ix, con
         const uint32_t op = d.z, end = op + (d.y & 0xFFFFFFu) + (d.w & 0xFFFFFFu);
         // the descriptors must tile [0, size): first at 0, each where the one before ends, the last at the block's size
         const bool okay = (i == 0 ? op == 0 : true) && (i + 1 < blk.nseq ? bd[i + 1].z == end : end == e.dst_size) && end >= op && end <= e.dst_size;
-        if (!okay) { atomicOr(flags, 2u); continue; }
+        if (!okay) { ixt_fail(flags); continue; }
         for (uint32_t k = (op + 63u) >> 6; (k << 6) < end; k++) T[k] = i;                 // I hold output positions 64k in [op, end)
     }
 }
@@ -600,7 +620,7 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ 
         }
         if (count_it) { atomicAdd((unsigned long long*)(flags + 26), (unsigned long long)n_turns); atomicAdd(flags + 28, n_pieces); atomicAdd(flags + 29, n_fromout); atomicMax(flags + 30, n_turns); }
     }
-    if (bad) atomicOr(flags, 2u);
+    if (bad) ixt_fail(flags);
     // this workgroup's bytes are in memory: count them into the region
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -636,7 +656,7 @@ __global__ __launch_bounds__(256) void k_pd_init(const uint8_t* __restrict__ fra
     const uint32_t b = (uint32_t)(gpos / block_size);
     if (b >= n) return;
     const BlockOut e = table[b];
-    if (e.dst_off != (uint64_t)b * block_size) { atomicOr(flags, 2u); return; }            // (all blocks but the last are full: checked when the index was made)
+    if (e.dst_off != (uint64_t)b * block_size) { ixt_fail(flags); return; }            // (all blocks but the last are full: checked when the index was made)
     const uint32_t i0 = (uint32_t)(gpos - e.dst_off);
     if (i0 >= e.dst_size) return;
     const uint32_t want = e.dst_size - i0 < IXT_TB ? e.dst_size - i0 : IXT_TB;
@@ -650,7 +670,7 @@ __global__ __launch_bounds__(256) void k_pd_init(const uint8_t* __restrict__ fra
         for (uint32_t q = 0; q < want; q++) { out[q] = frame[e.src_off + i0 + q]; pout[q] = IXP_DONE; }
         return;
     }
-    if (blk.nseq == 0) { atomicOr(flags, 2u); return; }
+    if (blk.nseq == 0) { ixt_fail(flags); return; }
     const uint32_t last = blk.nseq - 1;
     uint32_t sq = postab[(e.dst_off >> 6) + (i0 >> 6)];
     while (got < want && !bad) {
@@ -696,7 +716,7 @@ __global__ __launch_bounds__(256) void k_pd_init(const uint8_t* __restrict__ fra
         for (uint32_t q = 0; q < span; q++) { out[got + q] = origin[q]; pout[got + q] = IXP_DONE; }
         got += span;
     }
-    if (bad) atomicOr(flags, 2u);
+    if (bad) ixt_fail(flags);
     for (int o = 32; o; o >>= 1) open += __shfl_xor(open, o);
     if ((threadIdx.x & 63u) == 0 && open) atomicAdd(remaining + ((blockIdx.x * 4 + (threadIdx.x >> 6)) % IXP_STRIPES), open);
 }
@@ -722,7 +742,7 @@ __global__ __launch_bounds__(256) void k_pd_round(uint8_t* dst, uint32_t* ptr, c
         const uint64_t i = base + k * 64;
         cur[k] = i < total ? ptr[i] : IXP_DONE;
         st[k] = cur[k] < IXP_DONE ? 1u : 0u;
-        if (st[k] && cur[k] >= i) { atomicOr(flags, 2u); st[k] = 0; }  // (sources lie in front: anything else is a corrupted descriptor)
+        if (st[k] && cur[k] >= i) { ixt_fail(flags); st[k] = 0; }  // (sources lie in front: anything else is a corrupted descriptor)
     }
     // IXP_JUMPS steps along the trail per round (each word read may already be this round's: any value it has held is valid)
 #pragma unroll
@@ -734,7 +754,7 @@ __global__ __launch_bounds__(256) void k_pd_round(uint8_t* dst, uint32_t* ptr, c
         for (uint32_t k = 0; k < 4; k++) {
             if (st[k] != 1u) continue;
             if (v[k] >= IXP_DONE) { st[k] = (v[k] - IXP_DONE < round) ? 2u : 3u; }      // finished earlier: copy it; in this very round: not visible yet, wait here
-            else if (v[k] >= cur[k]) { atomicOr(flags, 2u); st[k] = 0; }
+            else if (v[k] >= cur[k]) { ixt_fail(flags); st[k] = 0; }
             else cur[k] = v[k];
         }
     }
@@ -753,7 +773,7 @@ __global__ __launch_bounds__(256) void k_pd_round(uint8_t* dst, uint32_t* ptr, c
 
 __global__ void k_pd_verdict(uint32_t* flags, const uint32_t* __restrict__ remaining)
 {
-    if (blockIdx.x == 0 && threadIdx.x < IXP_STRIPES && flags[IXT_FLAG] && !*flags && remaining[IXP_ROUNDS * IXP_STRIPES + threadIdx.x] != 0) atomicOr(flags, 2u);      // deeper than 2^16: the generic kernels
+    if (blockIdx.x == 0 && threadIdx.x < IXP_STRIPES && flags[IXT_FLAG] && !*flags && remaining[IXP_ROUNDS * IXP_STRIPES + threadIdx.x] != 0) ixt_fail(flags);      // deeper than 2^16: the generic kernels
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -333,7 +333,11 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             if (!ix_ev) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ix_ev = e; }
             IxHeader hd; memset(&hd, 0, sizeof(hd));
             bool have = false;
-            if (ix_pending && hipEventQuery((hipEvent_t)ix_ev) == hipSuccess) { memcpy(&hd, h_ix.p, sizeof(hd)); ix_pending = false; have = true; }
+            if (ix_pending && hipEventQuery((hipEvent_t)ix_ev) == hipSuccess) {
+                memcpy(&hd, h_ix.p, sizeof(hd)); ix_pending = false; have = true;
+                uint32_t decided = 0; memcpy(&decided, (const uint8_t*)h_ix.p + 32, 4);
+                ix_chain_hint = decided != 0;                              // (the last frame was decoded from its bytes' origins: expect the next one to be)
+            }
             if (!have && ix_seq_cap == 0) {
                 HIP_TRY(hipMemcpyAsync(&hd, d_index, sizeof(hd), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
@@ -349,7 +353,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             if (ix_seq_cap) {
                 const size_t dsrc_at = (ix_seq_cap + 64) * sizeof(SeqDesc);
                 if (desc.ensure(dsrc_at + (ix_seq_cap + 64) * 4) || seqcnt.ensure(256 + (size_t)n_max * (8 + 8 * IXL_PUB))) return make_err(LZ4F_ERROR_allocation_failed);
-                HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 128 + (j.linked ? 128 + (size_t)n_max * 8 : 0), st));      // flags (+ per block of a linked frame: the "done" word and the count of published ranges)
+                HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 256 + (j.linked ? (size_t)n_max * 8 : 0), st));      // flags (+ per block of a linked frame: the "done" word and the count of published ranges)
                 uint32_t* done = (uint32_t*)seqcnt.p + 64;
                 uint32_t lk = j.linked ? 1u : 0u;                                  // (bits 1..: chain gate, see k_copy_indexed)
                 if (j.linked) if (const char* gs = getenv("LZ4F_MI355X_CHAIN_GATE")) { const int gv = atoi(gs); if (gv > 0 && gv < (1 << 20)) lk |= (uint32_t)gv << 1; }
@@ -364,11 +368,11 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 const bool trace_can = !getenv("LZ4F_MI355X_NO_TRACE") && !getenv("LZ4F_MI355X_NO_RESOLVE") && (j.block_size & 63u) == 0;
                 // (pointer doubling does ~12 GiB/s on text whatever the framing; hop by hop it is 1.3 GiB/s, which only pays where
                 // there is no block-level parallelism - linked frames; independent blocks then stay with the copier workgroups, 4.8 GiB/s)
-                const bool can_double = (ix_dense_hint || getenv("LZ4F_MI355X_TRACE_ALWAYS")) && trace_span <= IXP_MAX_SPAN && !getenv("LZ4F_MI355X_NO_DOUBLING");
+                const bool can_double = (ix_dense_hint || ix_chain_hint || getenv("LZ4F_MI355X_TRACE_ALWAYS")) && trace_span <= IXP_MAX_SPAN && !getenv("LZ4F_MI355X_NO_DOUBLING");
                 uint32_t gate = !trace_can ? 0u : getenv("LZ4F_MI355X_TRACE_ALWAYS") ? 2u : (j.linked || can_double) ? 1u : 0u;
                 if (gate && postab.ensure((size_t)(trace_span >> 6) * 4 + 512 + ((size_t)(trace_span >> IXT_REGION_LOG) + 4) * 4)) gate = 0;      // (no memory for the position table: the copiers do it)
                 if (gate && can_double)                                        // (dense by the sequence density: no need to resolve anything)
-                    hipLaunchKernelGGL(k_dense_gate, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, gate, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, 1u);
+                    hipLaunchKernelGGL(k_dense_gate, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, gate, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, 1u, 1u);
                 uint32_t* dsrc = (uint32_t*)((uint8_t*)desc.p + dsrc_at);
                 if (getenv("LZ4F_MI355X_NO_RESOLVE")) dsrc = nullptr;
                 else
@@ -382,7 +386,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 }
                 // dense frames (text): no chain at all, every output byte traced to its literal (see k_trace_copy)
                 {
-                    hipLaunchKernelGGL(k_dense_gate, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, gate, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, 0u);
+                    hipLaunchKernelGGL(k_dense_gate, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, gate, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, 0u, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u);
                     if (gate) {
                         hipLaunchKernelGGL(k_build_postab, dim3(n_max, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u), dim3(256), 0, st, d_index, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max,
                                            (const SeqDesc*)desc.p, (uint32_t*)postab.p, (uint32_t*)seqcnt.p);
@@ -428,6 +432,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             }
             // this call's header for the next call (no wait here)
             HIP_TRY(hipMemcpyAsync(h_ix.p, d_index, sizeof(IxHeader), hipMemcpyDeviceToHost, st));
+            if (indexed) HIP_TRY(hipMemcpyAsync((uint8_t*)h_ix.p + 32, (uint32_t*)seqcnt.p + IXT_DECIDED, 4, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipEventRecord((hipEvent_t)ix_ev, st));
             ix_pending = true;
         }

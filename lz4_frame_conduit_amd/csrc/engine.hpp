@@ -61,6 +61,7 @@ struct lz4f_mi355x_engine {
     lz4f::PinBuf h_in, h_out, h_small;
     // indexed decode: the last index header seen (copied back asynchronously) sizes the descriptor workspace of the next call
     lz4f::PinBuf h_ix; void* ix_ev = nullptr; bool ix_pending = false; size_t ix_seq_cap = 0; uint32_t ix_entries_hint = 0;
+    bool ix_chain_hint = false;                            // the last indexed frame was judged dense on the device (most sequences on the match chain)
     bool ix_dense_hint = false;                            // the last index header seen was of a stream of short sequences
     bool  timing = false;
     void* ev[20] = {nullptr};      // hipEvent_t pairs (begin,end) per timing slot
