@@ -10,6 +10,8 @@ L = _ffi.lib()
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 n_mut = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 data = datagen.structured(1 << 20, 77) + datagen.synth50(1 << 20, 5).tobytes()
+if os.environ.get('DATA') == 'text':                # dense data: the frame goes through the pointer-doubling kernels
+    data = datagen.synth_text(2 << 20, 7).tobytes()
 frame = oracle.conduit_compress(data, oracle.mkprefs(bsid=4, indep=0))
 cap = len(data) + 8
 diff = 0; t0 = time.time()
