@@ -117,7 +117,7 @@ lz4f_mi355x_engine::~lz4f_mi355x_engine()
 {
     (void)hipSetDevice(device);
     (void)hipStreamSynchronize((hipStream_t)stream);
-    desc.release(); seqcnt.release(); selfix.release(); selfcnt.release();
+    desc.release(); seqcnt.release(); selfix.release(); selfcnt.release(); postab.release(); pdbuf.release();
     info.release(); recs.release(); table.release(); blk_bytes.release(); res.release(); bad.release();
     d_in.release(); d_out.release();
     h_in.release(); h_out.release(); h_small.release();
