@@ -23,6 +23,10 @@
 //                     workgroup's output are set aside and replayed when that one is far enough.
 //   k_selfindex_walk / k_selfindex_scan   linked frames without an index: a lane per block walks the payload (parsing
 //                     needs no history), a scan places the blocks, the entries are written - then everything above
+//   k_dense_gate / k_build_postab / k_pd_init / k_pd_round / k_pd_verdict   DENSE frames (text, repetitive records: most
+//                     sequences on the match chain) are not walked as chains at all: every output byte takes one hop back
+//                     to where it comes from, then pointer doubling over a word per output byte (see below)
+//   k_trace_copy      the same origins hop by hop, for when that scratch cannot be had
 #pragma once
 #include "common.cuh"
 #include "decode.cuh"
