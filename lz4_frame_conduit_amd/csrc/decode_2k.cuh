@@ -33,8 +33,6 @@ struct SeqDesc { uint32_t x, y, z, w; };
 
 __device__ __forceinline__ uint32_t max_seq_per_block(uint32_t block_size) { return block_size / 4 + 2; }
 
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 // issue the direct-to-LDS loads of payload bytes [s*STAGE, min(csize, (s+1)*STAGE + OVER)) into `slot`
 __device__ __forceinline__ void pk_stage_issue(uint8_t* slot, const uint8_t* __restrict__ in, uint32_t csize, uint32_t s)

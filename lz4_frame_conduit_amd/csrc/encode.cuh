@@ -5,14 +5,11 @@
 // hash-table match finding and token / literal / offset / match-length emission.
 //
 // MI355X mapping (not a port of the CPU loop, which probes one position at a time):
-//   pass E1  find_matches  one wave per CHUNK of a frame block.  The 64 lanes probe 64 positions at
-//                          once against a private 4096 x u16 hash table in LDS (8 KiB per wave),
-//                          verify the candidates with a gather from the input, __ballot picks the
-//                          first hit, the wave extends it backwards/forwards 8 B per lane, and one
-//                          8-byte sequence record {literals, match length, offset} is appended.
-//                          Misses grow the probe stride like the CPU encoder's skip acceleration
-//                          (one stride step per 64 probes).  The table is pre-seeded from the
-//                          <= 64 KiB in front of the chunk, so chunking costs no matches.
+//   pass E1  find_matches  one workgroup per run of 64 KiB chunks.  The last 128 KiB of input (the chunk and its 64 KiB window)
+//                          and ONE hash table (8192 x {u16 position, u8 tag}) live in LDS; the chunk is cut into 128-byte slices
+//                          which the 16 waves take in order from a counter, each parsing its slices greedily like the CPU encoder
+//                          (64 positions per probe step, the stride grows after misses), verifying and extending in LDS;
+//                          the slices' sequence lists are merged into the chunk's record list {literals, match length, offset}.
 //   pass S   layout        sizes of all chunks/blocks (raw fallback when a block would not shrink),
 //                          exclusive scan -> final byte offset of every chunk in the frame; writes
 //                          size words, frame header, EndMark.
@@ -26,18 +23,6 @@
 
 namespace lz4f {
 
-constexpr uint32_t HASH_LOG = 12;
-#ifndef E1_TABLE_SIXTEENTHS
-#define E1_TABLE_SIXTEENTHS 15
-#endif
-// entries per wave.  (E1_TABLE_SIXTEENTHS / 16 of 2^HASH_LOG: the table is what bounds the waves per CU - 15/16 of 4096
-// entries at 3 bytes is 11.25 KiB, 14 waves in a CU's 160 KiB instead of 13.)
-constexpr uint32_t HASH_SIZE = (E1_TABLE_SIXTEENTHS << HASH_LOG) >> 4;
-__device__ __forceinline__ uint32_t hash_slot(uint32_t hv)
-{
-    const uint32_t top = hv >> (32 - HASH_LOG);
-    return E1_TABLE_SIXTEENTHS == 16 ? top : (top * E1_TABLE_SIXTEENTHS) >> 4;
-}
 constexpr uint32_t MFLIMIT = 12, LASTLIT = 5, MINMATCH = 4;
 
 struct ChunkInfo {           // 32 bytes, one per chunk
@@ -64,7 +49,9 @@ struct EncGeom {
     uint32_t header_size;
     uint8_t  header[20];
     uint32_t max_rec_per_chunk;  // record slots per chunk
-    uint32_t seed_stride, seed_dense;   // table pre-seed: every seed_stride-th position, last seed_dense bytes densely
+    uint32_t seed_stride;        // pass E1: a run's 64 KiB of history go into the table at every seed_stride-th position
+    uint32_t tiles_per_wg;       // pass E1: consecutive chunks a workgroup takes
+    uint32_t e1_solo;            // (development) pass E1: bit 0 - only the workgroup's first wave parses (the sequential parse, for comparing ratios); bit 1 - nothing is parsed (the cost of everything else)
 };
 
 __device__ __forceinline__ uint32_t len_ext_bytes(uint32_t v) { return v >= 15 ? (v - 15) / 255 + 1 : 0; }
@@ -89,369 +76,79 @@ __device__ __forceinline__ uint64_t ld64_guard(const uint8_t* p, const uint8_t* 
     return v;
 }
 
-// ------------------------------- pass E1 -------------------------------------------------------
-#ifndef E1_TAG_BITS
-#define E1_TAG_BITS 8
+// ------------------------------- pass E1, one workgroup per run of tiles ------------------------
+// A workgroup searches one 64 KiB tile (= chunk) at a time and goes through a run of consecutive tiles.  What its waves
+// share lives in LDS: the last 128 KiB of input (the tile and the 64 KiB window in front of it) in a ring, and ONE hash
+// table (8192 x u16, the table shape liblz4 uses for small inputs) that is kept up to date across tiles - so the input is
+// read from HBM once (plus 64 KiB of history per run), a candidate is verified and a match extended by LDS reads, and
+// nothing is seeded per chunk.
+//   * The tile is cut into 256-byte slices which the waves take from a counter in LDS, in order: at any time the waves
+//     work on neighbouring slices (a front of E1_WAVES x 256 bytes), so everything further back than the front is in the
+//     table when a position is probed.  A slice is parsed greedily like the CPU encoder does (64 positions per step, the
+//     stride grows after a step without a hit), from its first byte - or from where a match published by another wave
+//     ends, and not at all when such a match covers it.  Matches end at the tile's end, not the slice's.
+//   * A table entry is a position's low 16 bits.  Every entry therefore names exactly one position 1..65536 bytes back,
+//     and the ring holds that position's real bytes whoever wrote the entry (a wave further ahead included): a candidate
+//     is a match iff its bytes say so.
+//   * Slices are parsed as if nothing in front reached into them.  At the end of the tile a prefix maximum over the slices'
+//     last match ends says how much of each slice the slices in front have covered; sequences inside that are dropped, the
+//     one that straddles it is shortened, and the kept sequences of all slices are written out in order as the tile's
+//     record list.  What passes S and E2 see is a 64 KiB chunk, as before.
+constexpr uint32_t E1_TILE = 65536, E1_RING = 2 * E1_TILE, E1_RMASK = E1_RING - 1;
+#ifndef E1_SLICE_BYTES
+#define E1_SLICE_BYTES 128
 #endif
-constexpr uint32_t TAG_BITS = E1_TAG_BITS, TAG_MASK = (1u << TAG_BITS) - 1;
-typedef std::conditional<(E1_TAG_BITS > 8), uint16_t, uint8_t>::type tag_t;
-// grid: one wave per chunk (blockDim = 64 * WAVES_PER_WG)
-template <int WAVES_PER_WG>
-__global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches(const uint8_t* __restrict__ src, EncGeom g,
-                                                                    ChunkInfo* __restrict__ info, uint64_t* __restrict__ recs,
-                                                                    unsigned long long* prof = nullptr)
-{
-    __shared__ uint16_t s_table[WAVES_PER_WG][HASH_SIZE];
-    __shared__ tag_t s_tag[WAVES_PER_WG][HASH_SIZE];        // TAG_BITS more hash bits per entry: filters false candidates without touching memory
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t chunk = uni(blockIdx.x * WAVES_PER_WG + wave);
-    if (chunk >= g.n_chunks) return;
-    uint16_t* table = s_table[wave];
-    tag_t* tags = s_tag[wave];
-
-    const uint32_t blk = chunk / g.chunks_per_block, cib = chunk % g.chunks_per_block;
-    const uint64_t bstart = g.first_off + (uint64_t)blk * g.block_size;
-    const uint64_t bend_abs = (bstart + g.block_size < g.src_size) ? bstart + g.block_size : g.src_size;
-    const uint64_t cs_abs = bstart + (uint64_t)cib * g.chunk_size;
-    ChunkInfo* ci = info + chunk;
-    if (cs_abs >= bend_abs) {               // chunk beyond a short last block
-        if (lane == 0) { ci->nrec = 0; ci->first_lit = 0; ci->tail_lit = 0; ci->body_size = 0; }
-        return;
-    }
-    const uint64_t ce_abs = (cs_abs + g.chunk_size < bend_abs) ? cs_abs + g.chunk_size : bend_abs;
-    const uint64_t low_abs = g.linked ? 0 : bstart;                  // matches may not start before this
-    const uint32_t back = (uint32_t)((cs_abs - low_abs < 65536u) ? (cs_abs - low_abs) : 65536u);
-    const uint8_t* base = src + (cs_abs - back);                     // position 0
-    const uint8_t* rd_end = src + g.src_size;                        // nothing is read at or beyond this
-    const uint32_t cs = back, ce = back + (uint32_t)(ce_abs - cs_abs);
-    const uint32_t bend = back + (uint32_t)(bend_abs - cs_abs);
-    uint64_t* rec = recs + (uint64_t)chunk * g.max_rec_per_chunk;
-
-#ifdef E1_PROF
-    const unsigned long long pt_kernel = clock64();
+constexpr uint32_t E1_SLICE = E1_SLICE_BYTES, E1_NSLICE = E1_TILE / E1_SLICE, E1_REC_PER_SLICE = E1_SLICE / MINMATCH;
+constexpr uint32_t E1_HASH_LOG = 13;                 // 8192 entries: a position's low 16 bits + 8 more hash bits in a byte array of their own
+#ifndef E1_WAVES
+#define E1_WAVES 16
 #endif
-    // clear + pre-seed the table with the history in front of the chunk.  A 4096-entry table cannot hold
-    // 64 KiB of positions, and later inserts win: seed the whole window sparsely (every SEED_STRIDE-th position,
-    // roughly the density the skip-accelerated search itself leaves behind), then the last SEED_DENSE bytes densely.
-    for (uint32_t i = lane; i < HASH_SIZE / 2; i += WAVE) ((uint32_t*)table)[i] = 0;
-    for (uint32_t i = lane; i < HASH_SIZE * sizeof(tag_t) / 4; i += WAVE) ((uint32_t*)tags)[i] = 0;
-    if (back >= 4) {
-        const uint32_t dense_from = back > g.seed_dense ? back - g.seed_dense : 0;
-        const uint32_t ss = g.seed_stride;
-        constexpr int SEED_IN_FLIGHT = 16;                                           // loads in flight per wave (registers are plentiful: LDS bounds the occupancy)
-        uint32_t q = 0;
-        if (ss == 4) {
-            // every 4th position: 16 bytes per lane hold four of them, a wave-load covers 1 KiB (a quarter of the load instructions)
-            const uint32_t span = dense_from & ~1023u;
-            for (; q < span; q += SEED_IN_FLIGHT * 1024) {
-                uint4 vv[SEED_IN_FLIGHT];
-#pragma unroll
-                for (int u = 0; u < SEED_IN_FLIGHT; u++) { const uint32_t p = q + u * 1024 + lane * 16; const uint4_ua t = *(const uint4_ua*)(base + (p < span ? p : 0u)); vv[u] = uint4{t.x, t.y, t.z, t.w}; }
-#pragma unroll
-                for (int u = 0; u < SEED_IN_FLIGHT; u++) {
-                    const uint32_t p = q + u * 1024 + lane * 16;
-                    if (p < span) {
-                        const uint32_t w[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
-#pragma unroll
-                        for (int k = 0; k < 4; k++) { const uint32_t hv = w[k] * 2654435761u; table[hash_slot(hv)] = (uint16_t)(p + 4 * k); tags[hash_slot(hv)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
-                    }
-                }
-            }
-            q = span;
-        }
-        for (; q < dense_from; q += SEED_IN_FLIGHT * WAVE * ss) {
-            uint32_t pp[SEED_IN_FLIGHT], vv[SEED_IN_FLIGHT];
-#pragma unroll
-            for (int u = 0; u < SEED_IN_FLIGHT; u++) { pp[u] = q + (u * WAVE + lane) * ss; vv[u] = ld32(base + (pp[u] < dense_from ? pp[u] : 0u)); }
-#pragma unroll
-            for (int u = 0; u < SEED_IN_FLIGHT; u++) if (pp[u] < dense_from) { const uint32_t hv = vv[u] * 2654435761u; table[hash_slot(hv)] = (uint16_t)pp[u]; tags[hash_slot(hv)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
-        }
-        for (uint32_t q = dense_from; q + 4 <= back; q += SEED_IN_FLIGHT * WAVE) {       // (inserted in position order: later ones win)
-            uint32_t vv[SEED_IN_FLIGHT];
-#pragma unroll
-            for (int u = 0; u < SEED_IN_FLIGHT; u++) { const uint32_t p = q + u * WAVE + lane; vv[u] = ld32(base + (p + 4 <= back ? p : 0u)); }
-#pragma unroll
-            for (int u = 0; u < SEED_IN_FLIGHT; u++) {
-                const uint32_t p = q + u * WAVE + lane;
-                if (p + 4 <= back) { const uint32_t hv = vv[u] * 2654435761u; table[hash_slot(hv)] = (uint16_t)p; tags[hash_slot(hv)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
-            }
-        }
-    }
-
-    uint32_t nrec = 0, first_lit = 0, body = 0;
-    uint32_t anchor = cs;
-    // developer aid (-DE1_PROF, tools/e1_prof.py): cycles of one wave per phase of the search loop
-#ifdef E1_PROF
-    unsigned long long pt_probe = 0, pt_verify = 0, pt_ext = 0, pt_restart = 0, pn_iter = 0, pn_ver = 0;
-    const unsigned long long pt_begin = clock64();
-#define E1P(x) x
+#ifdef E1_DEBUG          // development: every loop bounded, counts of the bounds hit in the scratch buffer's last words
+#define E1DBG(...) __VA_ARGS__
 #else
-#define E1P(x)
+#define E1DBG(...)
 #endif
-    // a match may start at p iff p + 4 <= ce and p + MFLIMIT <= bend; it may end at min(ce, bend - LASTLIT).
-    // Blocks shorter than MFLIMIT+1 bytes are literals only (Appendix A.2).
-    const uint32_t blen = (uint32_t)(bend_abs - bstart), clen = ce - cs;
-    bool searchable = blen >= MFLIMIT + 1 && clen >= MINMATCH;
-    uint32_t last_start = 0, end_lim = 0;
-    if (searchable) {
-        last_start = (ce - MINMATCH < bend - MFLIMIT) ? ce - MINMATCH : bend - MFLIMIT;
-        end_lim = (ce < bend - LASTLIT) ? ce : bend - LASTLIT;
-        searchable = last_start >= cs;
-    }
-    if (searchable) {
-        // The search is latency-bound (a stream load, a table probe and a candidate gather per step), so two probe
-        // steps are kept in flight: step B = "the step after A if A finds nothing" is probed and inserted
-        // speculatively while A's candidate gather is still outstanding, and the stream loads run one more step
-        // ahead.  When A hits, B's table inserts (and A's beyond the hit) are rolled back from the values they
-        // overwrote, so the table evolves exactly as in the one-step-at-a-time formulation.
-        const uint32_t hmul = 2654435761u;
-        auto stream = [&](uint32_t ipx, uint32_t stepx) -> uint32_t {           // my 4 bytes of the step at (ipx, stepx)
-            const uint32_t px = ipx + lane * stepx;
-            return ld32(base + (px <= last_start ? px : last_start));       // unconditional load (clamped): no branch, no early wait
-        };
-        uint32_t ip = cs, step = 1;
-        // stream queue: my 4 bytes for the next six steps along the all-miss path (A, B and two more iterations),
-        // so that the sequential input is always at least two iterations (~2 us) ahead of the probes
-        uint32_t s0, s1, s2, s3, s4, s5, ipN, stepN;
-        auto fill_queue = [&]() {
-            uint32_t i_ = ip, st_ = step;
-            s0 = stream(i_, st_); i_ += WAVE * st_; st_++;
-            s1 = stream(i_, st_); i_ += WAVE * st_; st_++;
-            s2 = stream(i_, st_); i_ += WAVE * st_; st_++;
-            s3 = stream(i_, st_); i_ += WAVE * st_; st_++;
-            s4 = stream(i_, st_); i_ += WAVE * st_; st_++;
-            s5 = stream(i_, st_); i_ += WAVE * st_; st_++;
-            ipN = i_; stepN = st_;
-        };
-        fill_queue();
-        E1P(const unsigned long long pt_seeded = clock64();)
-        while (ip <= last_start) {
-            E1P(__builtin_amdgcn_sched_barrier(0); const unsigned long long pq0 = clock64(); __builtin_amdgcn_sched_barrier(0); pn_iter++;)
-            const uint32_t seqA = s0;
-            // ---- probe A ----
-            const uint32_t pA = ip + lane * step;
-            const bool actA = pA <= last_start;
-            const uint32_t hvA = seqA * hmul, hA = hash_slot(hvA), tgA = (hvA >> (32 - TAG_BITS - HASH_LOG)) & TAG_MASK;
-            uint32_t eA = 0, tA = TAG_MASK + 1;
-            if (actA) { eA = table[hA]; tA = tags[hA]; table[hA] = (uint16_t)pA; tags[hA] = (tag_t)tgA; }
-            const uint32_t dA = (pA - eA) & 0xFFFFu;
-            const bool okA = actA && tA == tgA && dA != 0 && dA <= pA;            // same 20 hash bits: worth a look at the bytes
-            const uint32_t candA = pA - dA;
-            // ---- speculative probe B (next step if A misses) + stream prefetch for the step after B ----
-            const uint32_t ipB = ip + WAVE * step, stepB = step + 1;
-            const uint32_t seqB = s1;
-            const uint32_t pB = ipB + lane * stepB;
-            const bool actB = pB <= last_start;
-            const uint32_t hvB = seqB * hmul, hB = hash_slot(hvB), tgB = (hvB >> (32 - TAG_BITS - HASH_LOG)) & TAG_MASK;
-            uint32_t eB = 0, tB = TAG_MASK + 1;
-            if (actB) { eB = table[hB]; tB = tags[hB]; table[hB] = (uint16_t)pB; tags[hB] = (tag_t)tgB; }
-            const uint32_t dB = (pB - eB) & 0xFFFFu;
-            const bool okB = actB && tB == tgB && dB != 0 && dB <= pB;
-            const uint32_t candB = pB - dB;
-            const uint32_t ipC = ipB + WAVE * stepB, stepC = stepB + 1;
-            // A candidate is looked at in memory only when its lane passed the 20-bit tag filter (in literal regions almost
-            // every step skips memory altogether), and then verification and extension are ONE round trip: the wave loads
-            // the 64 bytes before and the 512 bytes from the probe position itself, on both sides; the candidate is a match
-            // iff the first four bytes agree.  (A separate 4-byte gather first would cost a second trip on every match.)
-            uint64_t cA = __ballot(okA), cB = __ballot(okB);
-            E1P(__builtin_amdgcn_sched_barrier(0); const unsigned long long pq1 = clock64(); __builtin_amdgcn_sched_barrier(0); pt_probe += pq1 - pq0; pn_ver += (cA | cB) ? 1 : 0;)
-            bool hitB = false, found = false;
-            uint32_t L = 0, mp = 0, mc = 0, dist = 0, room = 0;
-            const uint32_t kb = lane + 1;
-            uint8_t bb0 = 0, bb1 = 1;
-            uint64_t x0 = 0;
-            uint32_t a0 = 0;
-            while (cA | cB) {
-                hitB = cA == 0;
-                if (!hitB) { L = (uint32_t)__builtin_ctzll(cA); cA &= cA - 1; } else { L = (uint32_t)__builtin_ctzll(cB); cB &= cB - 1; }
-                mp = __builtin_amdgcn_readlane(hitB ? pB : pA, L);
-                mc = __builtin_amdgcn_readlane(hitB ? candB : candA, L);
-                dist = mp - mc;
-                room = mp - anchor; if (mc < room) room = mc;
-                bb0 = 0; bb1 = 1;
-                if (kb <= room) { bb0 = base[mp - kb]; bb1 = base[mc - kb]; }
-                a0 = mp + lane * 8;
-                x0 = 0;
-                if (a0 < end_lim) x0 = ld64_guard(base + a0, rd_end) ^ ld64_guard(base + (a0 - dist), rd_end);
-                if (__builtin_amdgcn_readlane((uint32_t)x0, 0) == 0) { found = true; break; }       // mp + 4 <= end_lim always
-            }
-            E1P(__builtin_amdgcn_sched_barrier(0); const unsigned long long pq2 = clock64(); __builtin_amdgcn_sched_barrier(0); pt_verify += pq2 - pq1;)
-            if (!found) {                                                           // both steps missed: advance two steps, top up the queue
-                ip = ipC; step = stepC;
-                s0 = s2; s1 = s3; s2 = s4; s3 = s5;
-                s4 = stream(ipN, stepN); ipN += WAVE * stepN; stepN++;
-                s5 = stream(ipN, stepN); ipN += WAVE * stepN; stepN++;
-                continue;
-            }
-            // roll back the inserts the greedy parse does not make: lanes beyond the hit (and all of B when A hit).  Several
-            // lanes of a step can share a table slot (periodic data): a lane beyond the hit restoring "its" old value would
-            // also wipe the insert of a lane up to the hit, so those are written again afterwards.
-            if (!hitB) {
-                if (actB) { table[hB] = (uint16_t)eB; tags[hB] = (tag_t)tB; }
-                if (actA && lane > L) { table[hA] = (uint16_t)eA; tags[hA] = (tag_t)tA; }
-                if (actA && lane <= L) { table[hA] = (uint16_t)pA; tags[hA] = (tag_t)tgA; }
-            } else {
-                if (actB && lane > L) { table[hB] = (uint16_t)eB; tags[hB] = (tag_t)tB; }
-                if (actB && lane <= L) { table[hB] = (uint16_t)pB; tags[hB] = (tag_t)tgB; }
-            }
-            uint32_t mlen = 0;
-            {
-                // backward
-                const uint64_t ne = __ballot(!(kb <= room && bb0 == bb1));
-                uint32_t nb = ne ? (uint32_t)__builtin_ctzll(ne) : WAVE;
-                if (nb == WAVE && room > WAVE) {                                   // rare: more than 64 bytes backwards
-                    uint32_t r2 = room - WAVE, m2 = mp - WAVE, c2 = mc - WAVE;
-                    while (r2) {
-                        const bool in = kb <= r2;
-                        const bool eq = in && base[m2 - kb] == base[c2 - kb];
-                        const uint64_t ne2 = __ballot(!eq);
-                        const uint32_t n2 = ne2 ? (uint32_t)__builtin_ctzll(ne2) : WAVE;
-                        nb += n2; m2 -= n2; c2 -= n2; r2 -= n2;
-                        if (n2 < WAVE) break;
-                    }
-                }
-                mp -= nb; mc -= nb; mlen += nb;
-                // forward: the first 512 bytes came with the verification; longer matches go on below
-                uint32_t g0 = 0;
-                if (a0 < end_lim) { g0 = x0 ? (uint32_t)(__builtin_ctzll(x0) >> 3) : 8; const uint32_t r = end_lim - a0; if (g0 > r) g0 = r; }
-                const uint64_t stop0 = __ballot(g0 < 8);
-                bool more = false;
-                if (stop0) { const uint32_t f = (uint32_t)__builtin_ctzll(stop0); mlen += f * 8 + __builtin_amdgcn_readlane(g0, f); }
-                else { mlen += WAVE * 8; more = true; }
-                while (more) {                                                      // long matches: keep going, 512 bytes per round
-                    // (one round per trip: hipcc waits for each of these guarded loads separately, so a second round fetched
-                    // "for free" cost two more round trips - and a match of exactly 512 bytes, the end of the first window, is common)
-                    const uint32_t b0 = mp + mlen + lane * 8;
-                    uint64_t y0 = 0;
-                    if (b0 < end_lim) y0 = ld64_guard(base + b0, rd_end) ^ ld64_guard(base + (b0 - dist), rd_end);
-                    uint32_t h0 = 0;
-                    if (b0 < end_lim) { h0 = y0 ? (uint32_t)(__builtin_ctzll(y0) >> 3) : 8; const uint32_t r = end_lim - b0; if (h0 > r) h0 = r; }
-                    const uint64_t s0 = __ballot(h0 < 8);
-                    if (s0) { const uint32_t f = (uint32_t)__builtin_ctzll(s0); mlen += f * 8 + __builtin_amdgcn_readlane(h0, f); break; }
-                    mlen += WAVE * 8;
-                }
-            }
-            E1P(__builtin_amdgcn_sched_barrier(0); const unsigned long long pq3 = clock64(); __builtin_amdgcn_sched_barrier(0); pt_ext += pq3 - pq2;)
-            // append the sequence record (every lane stores the same 8 bytes: no lane-predicated branch in this loop)
-            const uint32_t lit = mp - anchor;
-            rec[nrec] = pack_rec(lit, mlen, dist);
-            if (nrec == 0) first_lit = lit;
-            body += seq_size(lit, mlen);
-            nrec++;
-            anchor = ip = mp + mlen;
-            step = 1;
-            if (nrec >= g.max_rec_per_chunk) break;          // cannot happen with chunk/4+1 slots; belt and braces
-            // like the CPU encoder, also index ip-2; its bytes are requested together with the refilled stream queue
-            const bool ins2 = ip >= 2 + cs && ip + 2 <= ce;
-            const uint32_t q2 = ins2 ? ip - 2 : cs;
-            const uint32_t v2 = ld32(base + q2);
-            fill_queue();
-            if (ins2) { const uint32_t hv = v2 * hmul; table[hash_slot(hv)] = (uint16_t)q2; tags[hash_slot(hv)] = (tag_t)(hv >> (32 - TAG_BITS - HASH_LOG)); }
-            E1P(__builtin_amdgcn_sched_barrier(0); pt_restart += clock64() - pq3; __builtin_amdgcn_sched_barrier(0);)
-        }
-        E1P(if (prof && chunk == 1000 && lane == 0) { prof[64] = clock64() - pt_begin; prof[65] = pt_seeded - pt_begin; prof[66] = pt_probe; prof[67] = pt_verify; prof[68] = pt_ext; prof[69] = pt_restart; prof[70] = pn_iter; prof[71] = pn_ver; prof[72] = nrec; prof[73] = pt_begin - pt_kernel; })
-    }
-    if (lane == 0) { ci->nrec = nrec; ci->first_lit = first_lit; ci->tail_lit = ce - anchor; ci->body_size = body; }
-}
+#define E1_DBG_AT (((uint64_t)gridDim.x) * (2 * E1_NSLICE * E1_REC_PER_SLICE))
+struct alignas(16) E1Shared {
+    uint16_t table[1u << E1_HASH_LOG];       // (table and tags first: LDS offsets below 64 KiB fit a DS instruction's offset field)
+    uint8_t  tags[1u << E1_HASH_LOG];
+    uint32_t s_end[2][E1_NSLICE];            // per slice: end of its last match (0: none); by tile parity
+    uint8_t  s_n[2][E1_NSLICE];              // per slice: sequences found
+    uint32_t next, cov;                      // next slice to hand out; furthest match end published so far
+    uint32_t first;                          // the tile's first slice is done
+    uint32_t cur[16];                        // per wave: the slice it has (a lower bound while it is between slices; ~0 when it is through with the tile)
+    uint32_t pieces[2];                      // 4 KiB pieces of the NEXT tile already requested (by tile parity)
+    uint32_t mode, hits;                     // 0: density of the data not known yet, 1: sparse (long sequences), 2: dense; sequences found while it is not known
+    uint32_t idle[64];                       // where lanes 1..63 point their share of a wave-wide atomic
+    alignas(16) uint8_t ring[E1_RING + 16];  // + the first 16 bytes again, so that a read across the end needs no wrap
+};
+static_assert(sizeof(E1Shared) <= 163840, "one workgroup per CU");
+static_assert(64 * E1_WAVES >= E1_NSLICE, "a thread per slice when the lists are merged");
+#ifndef E1_GRAB
+#define E1_GRAB 8
+#endif
+constexpr uint32_t E1_GRAB_SPARSE = E1_GRAB, E1_PROBE_SLICES = 16, E1_DENSE_HITS = 24;
 
-// ------------------------------- pass S --------------------------------------------------------
-// one workgroup of 1024 threads: per-block sizes, then a chunked exclusive scan over the blocks
-__global__ __launch_bounds__(1024) void k_layout(EncGeom g, ChunkInfo* __restrict__ info, BlockOut* __restrict__ table,
-                                                 uint32_t* __restrict__ blk_bytes /* n_blocks scratch */,
-                                                 uint8_t* __restrict__ dst, uint64_t dst_cap, ResultRec* __restrict__ res)
+// 4 / 8 bytes at any byte position of the ring.  (A byte-unaligned ds_read_b32 / _b64 is legal on gfx950 but keeps the LDS busy
+// for ~20 cycles per wave instruction - measured: SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS - so the reads are dword-aligned and the
+// bytes are picked with v_alignbyte.)
+struct __attribute__((aligned(4))) e1_w2 { uint32_t a, b; };
+struct __attribute__((aligned(4))) e1_w3 { uint32_t a, b, c; };
+__device__ __forceinline__ uint32_t e1_ld32(const uint8_t* ring, uint32_t pos)
 {
-    __shared__ uint64_t s_part[1024];
-    __shared__ uint64_t s_carry;
-    const uint32_t t = threadIdx.x;
-    // 1) per block: walk its chunks, fix carries, decide raw
-    for (uint32_t b = t; b < g.n_blocks; b += 1024) {
-        const uint64_t bstart = g.first_off + (uint64_t)b * g.block_size;
-        const uint32_t blen = (uint32_t)((bstart + g.block_size < g.src_size) ? g.block_size : g.src_size - bstart);
-        ChunkInfo* ci = info + (uint64_t)b * g.chunks_per_block;
-        const uint32_t nch = (blen + g.chunk_size - 1) / g.chunk_size;
-        uint32_t carry = 0, total = 0;
-        // (eight summaries are fetched together: one thread walks a block's chunks, and a load per step would make this
-        // kernel a chain of 32 memory round trips)
-        for (uint32_t c0 = 0; c0 < nch; c0 += 8) {
-            uint4 x[8];                             // {nrec, first_lit, tail_lit, body_size}
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) x[k] = (c0 + k < nch) ? *(const uint4*)&ci[c0 + k] : uint4{0u, 0u, 0u, 0u};
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                const uint32_t c = c0 + k;
-                if (c >= nch) break;
-                *(uint2*)&ci[c].carry_in = uint2{carry, (c + 1 == nch) ? 2u : 0u};      // carry_in, flags
-                ci[c].out_off = total;              // relative for now
-                if (x[k].x) {
-                    total += x[k].w + carry + len_ext_bytes(x[k].y + carry) - len_ext_bytes(x[k].y);
-                    carry = x[k].z;
-                } else carry += x[k].z;
-            }
-        }
-        total += 1 + len_ext_bytes(carry) + carry;  // final literal-only sequence
-        const bool raw = total >= blen;             // LZ4F stores raw when it does not fit blockSize-1
-        const uint32_t payload = raw ? blen : total;
-        if (raw) for (uint32_t c = 0; c < nch; c++) ci[c].flags |= 1u;
-        table[b].word = raw ? (blen | 0x80000000u) : total;
-        table[b].dst_off = bstart - g.first_off;
-        table[b].dst_size = blen;
-        blk_bytes[b] = 4 + payload + 4 * g.block_checksum;
-    }
-    __syncthreads();
-    // 2) exclusive scan of blk_bytes in tiles of 1024
-    if (t == 0) s_carry = g.header_size;
-    __syncthreads();
-    for (uint32_t base = 0; base < g.n_blocks; base += 1024) {
-        const uint32_t b = base + t;
-        const uint64_t v = (b < g.n_blocks) ? blk_bytes[b] : 0;
-        s_part[t] = v;
-        __syncthreads();
-        for (uint32_t off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan
-            uint64_t add = (t >= off) ? s_part[t - off] : 0;
-            __syncthreads();
-            s_part[t] += add;
-            __syncthreads();
-        }
-        const uint64_t excl = s_carry + s_part[t] - v;
-        if (b < g.n_blocks) table[b].src_off = excl + 4;          // payload follows the size word
-        __syncthreads();
-        if (t == 1023) s_carry += s_part[1023];
-        __syncthreads();
-    }
-    const uint64_t frame_size = s_carry + (g.write_endmark ? 4 : 0);
-    const bool fits = frame_size <= dst_cap;
-    // 3) absolute chunk offsets, size words, header, EndMark
-    if (fits) {
-        for (uint32_t b = t; b < g.n_blocks; b += 1024) {
-            const uint64_t pay = table[b].src_off;
-            const uint32_t w = table[b].word;
-            dst[pay - 4] = (uint8_t)w; dst[pay - 3] = (uint8_t)(w >> 8); dst[pay - 2] = (uint8_t)(w >> 16); dst[pay - 1] = (uint8_t)(w >> 24);
-            ChunkInfo* ci = info + (uint64_t)b * g.chunks_per_block;
-            const uint32_t blen = table[b].dst_size;
-            const uint32_t nch = (blen + g.chunk_size - 1) / g.chunk_size;
-            for (uint32_t c0 = 0; c0 < nch; c0 += 8) {
-                uint64_t rel[8];
-#pragma unroll
-                for (uint32_t k = 0; k < 8; k++) rel[k] = (c0 + k < nch) ? ci[c0 + k].out_off : 0;
-#pragma unroll
-                for (uint32_t k = 0; k < 8; k++)
-                    if (c0 + k < nch) ci[c0 + k].out_off = (w >> 31) ? pay + (uint64_t)(c0 + k) * g.chunk_size : pay + rel[k];
-            }
-        }
-        if (t < g.header_size) dst[t] = g.header[t];
-        if (t < 4 && g.write_endmark) dst[s_carry + t] = 0;
-    }
-    if (t == 0 && res) {
-        res->size = fits ? frame_size : 0; res->consumed = g.src_size - g.first_off;
-        res->status = fits ? ST_OK : ST_DSTSMALL; res->n_blocks = g.n_blocks; res->first_bad_block = 0xFFFFFFFFu; res->flags = g.header[4];
-    }
-    if (!fits) for (uint32_t c = t; c < g.n_chunks; c += 1024) info[c].flags |= 4u;   // tell pass E2 to do nothing
+    const uint32_t i = pos & E1_RMASK;
+    const e1_w2 w = *(const e1_w2*)(ring + (i & ~3u));
+    return __builtin_amdgcn_alignbyte(w.b, w.a, i & 3u);
 }
-
-// ------------------------------- pass S spread over the machine --------------------------------
-// k_layout does everything from one workgroup: with 32 k chunks that is ~100 k memory requests through one CU (0.1 ms).
-// The same steps as three launches: per block on a wave (chunks in the lanes, carries and offsets by prefix sums),
-// the scan over the blocks on one workgroup, the per-chunk fix-up on a thread per chunk.  Same results (tools/emit_compare.py).
+__device__ __forceinline__ uint64_t e1_ld64(const uint8_t* ring, uint32_t pos)
+{
+    const uint32_t i = pos & E1_RMASK;
+    const e1_w3 w = *(const e1_w3*)(ring + (i & ~3u));
+    return (uint64_t)__builtin_amdgcn_alignbyte(w.b, w.a, i & 3u) | ((uint64_t)__builtin_amdgcn_alignbyte(w.c, w.b, i & 3u) << 32);
+}
+__device__ __forceinline__ uint32_t e1_mix(uint32_t v) { return v * 2654435761u; }
+__device__ __forceinline__ uint32_t e1_slot(uint32_t hv) { return hv >> (32 - E1_HASH_LOG); }
+__device__ __forceinline__ uint32_t e1_tag(uint32_t hv) { return (hv >> (24 - E1_HASH_LOG)) & 0xFFu; }
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t& total)
 {
     const uint32_t lane = lane_id();
@@ -461,6 +158,424 @@ __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t& total)
     total = __builtin_amdgcn_readlane(incl, 63);
     return incl - v;
 }
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) { const uint32_t t = __shfl_xor(v, s); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) v += __shfl_xor(v, s);
+    return v;
+}
+// minimum over lanes 0..15 (one DPP row), the same value to every lane
+__device__ __forceinline__ uint32_t wave_min16(uint32_t v)
+{
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, false); v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, false); v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, false); v = t < v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, false); v = t < v ? t : v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+}
+__device__ __forceinline__ uint32_t wave_excl_scan_max(uint32_t v)
+{
+    const uint32_t lane = lane_id();
+    uint32_t incl = v;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) { const uint32_t t = __shfl_up(incl, sft); if ((int)lane >= sft) incl = t > incl ? t : incl; }
+    const uint32_t ex = __shfl_up(incl, 1);
+    return lane == 0 ? 0u : ex;
+}
+constexpr uint32_t E1_PIECE_LOG = 12, E1_NPIECE = E1_TILE >> E1_PIECE_LOG;
+// 4 KiB piece pc of the tile at position nts: global -> ring, four LDS-DMA wave instructions.  (From inline asm: hipcc would
+// make every later LDS read wait for an LDS-DMA it knows about.  The issuing wave's s_waitcnt vmcnt covers it.)
+__device__ __forceinline__ void e1_dma_piece(E1Shared& sh, const uint8_t* __restrict__ src, uint64_t org, uint32_t nts, uint32_t pc)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t ring0 = (uint32_t)(uintptr_t)(lptr_t)sh.ring;
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        const uint32_t at = nts + (pc << E1_PIECE_LOG) + q * 1024u;
+        const uint8_t* gsrc = src + (org + at + lane * 16u);
+        const uint32_t ldst = uni(ring0 + (at & E1_RMASK));
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(ldst) : "memory");
+    }
+}
+
+// bytes [a, b) of the input (positions; abs = org + pos) -> ring.  16-byte units where a whole unit lies inside, single bytes at the ends.
+__device__ __forceinline__ void e1_fill(E1Shared& sh, const uint8_t* __restrict__ src, uint64_t org, uint32_t a, uint32_t b, uint32_t tid)
+{
+    constexpr uint32_t NT = 64 * E1_WAVES;
+    auto put = [&](uint32_t p) { const uint8_t v = src[org + p]; sh.ring[p & E1_RMASK] = v; if ((p & E1_RMASK) < 16) sh.ring[E1_RING + (p & E1_RMASK)] = v; };
+    const uint32_t a16 = (a + 15u) & ~15u, b16 = b & ~15u;
+    if (a16 < b16) {
+        for (uint32_t u = a16 + tid * 16; u < b16; u += NT * 16) {
+            const b16_ua t = *(const b16_ua*)(src + (org + u));
+            const uint32_t i = u & E1_RMASK;
+            *(uint4*)(sh.ring + i) = uint4{t.a, t.b, t.c, t.d};
+            if (i == 0) *(uint4*)(sh.ring + E1_RING) = uint4{t.a, t.b, t.c, t.d};
+        }
+        if (tid < a16 - a) put(a + tid);
+        if (tid < b - b16) put(b16 + tid);
+    } else {
+        for (uint32_t p = a + tid; p < b; p += NT) put(p);
+    }
+}
+
+// one record of a slice's list as the walk over it sees it: kept (possibly shortened) or dropped
+struct E1Walk {
+    uint32_t pos, cov, bend;                 // end of the record before; what the slices in front cover; block end
+    __device__ __forceinline__ bool step(uint64_t x, uint32_t& start, uint32_t& mlen)
+    {
+        const uint32_t lit = (uint32_t)(x & 0xFFFFFFu); mlen = (uint32_t)((x >> 24) & 0xFFFFFFu);
+        start = pos + lit;
+        const uint32_t end = start + mlen;
+        pos = end;
+        if (end <= cov) return false;
+        if (start < cov) {                                               // straddles: what is left of it, if that is still a match
+            const uint32_t ml2 = end - cov;
+            if (ml2 < MINMATCH || cov + MFLIMIT > bend) return false;
+            start = cov; mlen = ml2;
+        }
+        return true;
+    }
+};
+
+__global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* __restrict__ src, EncGeom g, ChunkInfo* __restrict__ info,
+                                                                uint64_t* __restrict__ recs, uint64_t* __restrict__ scratch)
+{
+    __shared__ E1Shared sh;
+    constexpr uint32_t NT = 64 * E1_WAVES;
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wave = uni(tid >> 6);
+    uint64_t* spec = scratch + (uint64_t)blockIdx.x * (2 * E1_NSLICE * E1_REC_PER_SLICE);      // this workgroup's slice lists (as found), for two tiles
+    const uint32_t c0 = blockIdx.x * g.tiles_per_wg;
+    const uint32_t c1 = (c0 + g.tiles_per_wg < g.n_chunks) ? c0 + g.tiles_per_wg : g.n_chunks;
+    // The chunks tile the stream: chunk c starts at first_off + c * 64 KiB.  Positions: the run's first tile starts at 65536,
+    // tile k at 65536 * (k + 1); up to 64 KiB of history sit in front of the first.  abs = org + pos.
+    const uint64_t s0 = g.first_off + (uint64_t)c0 * E1_TILE;
+    const uint64_t org = s0 - E1_TILE;                                   // (may wrap below zero: only ever used with pos >= the history's start)
+    uint32_t hist = 0, len0 = 0;
+    if (s0 < g.src_size) {
+        const uint64_t bstart0 = g.first_off + (uint64_t)(c0 / g.chunks_per_block) * g.block_size;
+        const uint64_t bend0 = (bstart0 + g.block_size < g.src_size) ? bstart0 + g.block_size : g.src_size;
+        const uint64_t low_abs = g.linked ? 0 : bstart0;
+        hist = (uint32_t)((s0 - low_abs < E1_TILE) ? s0 - low_abs : E1_TILE);
+        len0 = (uint32_t)((bend0 - s0 < E1_TILE) ? bend0 - s0 : E1_TILE);
+    }
+    const uint32_t hist0 = E1_TILE - hist;                               // first valid position
+    for (uint32_t i = tid; i < (1u << E1_HASH_LOG) / 2; i += NT) ((uint32_t*)sh.table)[i] = 0;
+    for (uint32_t i = tid; i < (1u << E1_HASH_LOG) / 4; i += NT) ((uint32_t*)sh.tags)[i] = 0;
+    e1_fill(sh, src, org, hist0, E1_TILE + len0, tid);                   // history + first tile
+    __syncthreads();
+    // the history's positions into the table, every seed_stride-th, in position order (later ones win)
+    for (uint32_t p = hist0 + tid * g.seed_stride; p < E1_TILE; p += NT * g.seed_stride)
+        if (p + 4 <= E1_TILE + len0) { const uint32_t hv = e1_mix(e1_ld32(sh.ring, p)); sh.table[e1_slot(hv)] = (uint16_t)p; sh.tags[e1_slot(hv)] = (uint8_t)e1_tag(hv); }
+
+    // ---- a tile's slice lists -> its record list.  One wave does it (the last one), on its own, while the others are already
+    // ---- searching the next tile: the lists and the per-slice words are double-buffered by tile parity.
+    auto merge = [&](uint32_t c, uint32_t par, uint32_t ts, uint32_t te, uint32_t bend, uint32_t nslice) {
+        constexpr uint32_t SP = E1_NSLICE / WAVE;                        // consecutive slices per lane
+        const uint32_t* s_end = sh.s_end[par];
+        const uint8_t* s_n = sh.s_n[par];
+        const uint64_t* spc = spec + (size_t)par * (E1_NSLICE * E1_REC_PER_SLICE);
+        const uint32_t s_lo = lane * SP;
+        // what the slices in front of a slice have covered = the maximum of their last match ends
+        uint32_t lmax = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < SP; j++) { const uint32_t e = (s_lo + j < nslice) ? s_end[s_lo + j] : 0u; lmax = e > lmax ? e : lmax; }
+        uint32_t cov0 = wave_excl_scan_max(lmax);
+        if (cov0 < ts) cov0 = ts;
+        // (all of a lane's lists are requested at once - their counts, and the first two records of each, which is all that
+        // most lists have: one memory round trip for the wave instead of one per list)
+        uint32_t nn[SP]; ulonglong2 x01[SP];
+#pragma unroll
+        for (uint32_t j = 0; j < SP; j++) nn[j] = (s_lo + j < nslice) ? s_n[s_lo + j] : 0u;
+#pragma unroll
+        for (uint32_t j = 0; j < SP; j++) x01[j] = *(const ulonglong2*)(spc + (nn[j] ? s_lo + j : 0u) * E1_REC_PER_SLICE);
+        // first walk: how many records are kept, where the lane's first kept one starts, the encoded size of its others
+        uint32_t kept = 0, f_start = 0, f_mlen = 0, last_end = 0, body = 0;
+        {
+            uint32_t cov = cov0;
+#pragma unroll
+            for (uint32_t j = 0; j < SP; j++) {
+                const uint32_t sj = s_lo + j, n = nn[j];
+                const uint64_t* lst = spc + sj * E1_REC_PER_SLICE;
+                E1Walk w{ts + sj * E1_SLICE, cov, bend};
+                for (uint32_t r = 0; r < n; r++) {
+                    uint32_t st, ml;
+                    if (!w.step(r == 0 ? x01[j].x : r == 1 ? x01[j].y : lst[r], st, ml)) continue;
+                    if (kept == 0) { f_start = st; f_mlen = ml; }
+                    else body += seq_size(st - last_end, ml);
+                    last_end = st + ml; kept++;
+                }
+                const uint32_t e = (sj < nslice) ? s_end[sj] : 0u; cov = e > cov ? e : cov;
+            }
+        }
+        uint32_t ktot;
+        uint32_t prev_end = wave_excl_scan_max(last_end);                // end of the last kept match in front of this lane's slices
+        const uint32_t off = wave_excl_scan(kept, ktot);                 // my place in the list
+        uint32_t kmax = wave_max(last_end);
+        if (prev_end < ts) prev_end = ts;
+        if (kmax < ts) kmax = ts;
+        const uint32_t f_lit = kept ? f_start - prev_end : 0u;
+        if (kept) body += seq_size(f_lit, f_mlen);
+        const uint32_t btot = wave_sum(body);
+        const uint64_t has = __ballot(kept != 0);
+        const uint32_t tile_first = has ? (uint32_t)__builtin_amdgcn_readlane(f_lit, (int)__builtin_ctzll(has)) : 0u;
+        // second walk: the kept records, literal runs counted from the kept match in front
+        {
+            uint64_t* out = recs + (uint64_t)c * g.max_rec_per_chunk + off;
+            uint32_t cov = cov0, jn = 0, le = prev_end;
+#pragma unroll
+            for (uint32_t j = 0; j < SP; j++) {
+                const uint32_t sj = s_lo + j, n = nn[j];
+                const uint64_t* lst = spc + sj * E1_REC_PER_SLICE;
+                E1Walk w{ts + sj * E1_SLICE, cov, bend};
+                for (uint32_t r = 0; r < n; r++) {
+                    const uint64_t x = r == 0 ? x01[j].x : r == 1 ? x01[j].y : lst[r];
+                    uint32_t st, ml;
+                    if (!w.step(x, st, ml)) continue;
+                    out[jn++] = pack_rec(st - le, ml, (uint32_t)(x >> 48));
+                    le = st + ml;
+                }
+                const uint32_t e = (sj < nslice) ? s_end[sj] : 0u; cov = e > cov ? e : cov;
+            }
+        }
+        ChunkInfo* ci = info + c;
+        if (lane == 0) {
+            ci->nrec = ktot; ci->first_lit = tile_first; ci->tail_lit = te - kmax; ci->body_size = btot;
+            sh.mode = (uint64_t)ktot * 64 > (uint64_t)(te - ts) ? 2u : 1u;      // how the next tiles hand out their slices
+        }
+    };
+
+    if (tid == 0) { sh.mode = 0; sh.cov = E1_TILE; sh.hits = 0; sh.first = 0; sh.next = 1; sh.pieces[0] = 0; sh.pieces[1] = 0; }
+    if (tid < 16) sh.cur[tid] = 0;
+    bool pend = false;                                                   // a tile whose lists are not merged yet
+    uint32_t p_c = 0, p_par = 0, p_ts = 0, p_te = 0, p_bend = 0, p_ns = 0;
+    __syncthreads();                                                     // the first tile is in the ring, the table is seeded, counters are set
+    for (uint32_t c = c0; c < c1; c++) {
+        const uint32_t k = c - c0;
+        const uint32_t ts = E1_TILE * (k + 1), par = k & 1u;
+        const uint32_t blk = c / g.chunks_per_block;
+        const uint64_t bstart = g.first_off + (uint64_t)blk * g.block_size;
+        const uint64_t bend_abs = (bstart + g.block_size < g.src_size) ? bstart + g.block_size : g.src_size;
+        const uint64_t cs_abs = s0 + (uint64_t)k * E1_TILE;
+        if (cs_abs >= bend_abs) {                                        // chunk beyond a short last block (uniform: the run ends here)
+            ChunkInfo* ci = info + c;
+            if (tid == 0) { ci->nrec = 0; ci->first_lit = 0; ci->tail_lit = 0; ci->body_size = 0; }
+            continue;
+        }
+        const uint32_t tlen = (uint32_t)((bend_abs - cs_abs < E1_TILE) ? bend_abs - cs_abs : E1_TILE);
+        const uint32_t te = ts + tlen;
+        const uint32_t bend = ts + (uint32_t)(bend_abs - cs_abs);        // block end (<= 4 MiB ahead)
+        const uint32_t blen = (uint32_t)(bend_abs - bstart);
+        const uint32_t nslice = (tlen + E1_SLICE - 1) / E1_SLICE;
+        uint32_t low = hist0;                                            // matches may not start before this
+        if (!g.linked) { const uint64_t back = cs_abs - bstart; if (back < (uint64_t)(ts - hist0)) low = ts - (uint32_t)back; }
+        uint64_t* spec_t = spec + (size_t)par * (E1_NSLICE * E1_REC_PER_SLICE);
+
+        uint32_t nlen = 0;                                               // the next tile of this run
+        const uint32_t nts = ts + E1_TILE;
+        if (c + 1 < c1) {
+            const uint32_t nblk = (c + 1) / g.chunks_per_block;
+            const uint64_t nbstart = g.first_off + (uint64_t)nblk * g.block_size;
+            const uint64_t nbend = (nbstart + g.block_size < g.src_size) ? nbstart + g.block_size : g.src_size;
+            const uint64_t ncs = cs_abs + E1_TILE;
+            if (ncs < nbend) nlen = (uint32_t)((nbend - ncs < E1_TILE) ? nbend - ncs : E1_TILE);
+        }
+        const bool nlen_full = nlen == E1_TILE;
+
+        E1DBG(const unsigned long long q0 = clock64();)
+        if (pend && wave == E1_WAVES - 1) {                              // (the others are searching already)
+            *(lane == 0 ? &sh.cur[wave] : &sh.idle[lane]) = 0xFFFFFFFFu;     // (holds no slice meanwhile; the one it takes afterwards lies beyond all that are held)
+            merge(p_c, p_par, p_ts, p_te, p_bend, p_ns);
+        }
+
+        E1DBG(const unsigned long long q1 = clock64();)
+        // ---- slices, in order, to whichever wave is free ----
+        // a match may start at p iff p + 4 <= te and p + MFLIMIT <= bend; it may end at min(te, bend - LASTLIT).
+        // Blocks shorter than MFLIMIT + 1 bytes are literals only (Appendix A.2).
+        const uint32_t end_lim = (te < bend - LASTLIT) ? te : bend - LASTLIT;
+        E1DBG(uint32_t dq = 0; unsigned long long a_deq = 0, a_probe = 0, a_hit = 0, n_step = 0, n_hit = 0, n_deq = 0;)
+        bool fresh = true;
+        for (;;) {
+            if ((g.e1_solo & 1u) && tid >= WAVE) break;
+            E1DBG(const unsigned long long z0 = clock64(); n_deq++;)
+            E1DBG(if (++dq > 100000) { if (lane == 0) atomicAdd((unsigned long long*)&scratch[E1_DBG_AT + 0], 1ull); break; })
+            // How many 128-byte slices to take: four where sequences are long (fewer restarts of the search, and of the stride), one
+            // where they are short - the waves then work within 2 KiB of each other, and what a position's nearest earlier
+            // occurrence usually is (text) has been indexed when it is probed.  A tile's first 2 KiB decide for a run's first tile,
+            // the later tiles go by the ones before.
+            uint32_t mode = uni(__hip_atomic_load(&sh.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            // The tile's first slice goes to the first wave alone, and the others start when it is through (a poll with a budget:
+            // going ahead without it costs ratio, nothing else).  Where the tile begins inside a long or periodic match - one hot
+            // table slot per distinct four bytes, always holding a position of whoever is furthest ahead - that slice finds it,
+            // publishes its end, and nobody searches what it covers.
+            const bool opener = fresh && wave == 0;
+            const uint32_t grab = (mode == 1 && !opener) ? E1_GRAB_SPARSE : 1u;
+            uint32_t si = 0;
+            if (!opener) {
+                if (fresh) for (uint32_t spin = 0; spin < 4096 && uni(__hip_atomic_load(&sh.first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0; spin++) __builtin_amdgcn_s_sleep(2);
+                si = uni(atomicAdd(lane == 0 ? &sh.next : &sh.idle[lane], grab));
+            }
+            fresh = false;
+            if (si >= nslice) { *(lane == 0 ? &sh.cur[wave] : &sh.idle[lane]) = 0xFFFFFFFFu; break; }
+            *(lane == 0 ? &sh.cur[wave] : &sh.idle[lane]) = si;
+            // The part of the window that every wave has left behind is where the next tile goes: once in a while, ask what the
+            // hindmost wave is at and request the 4 KiB pieces that have become free since (the atomic hands each piece to one wave).
+            if (nlen_full && (si & 31u) < grab) {
+                uint32_t mn = lane < E1_WAVES ? __hip_atomic_load(&sh.cur[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0xFFFFFFFFu;
+                mn = wave_min16(mn);
+                uint32_t ok_p = mn == 0xFFFFFFFFu ? 0u : (mn * E1_SLICE) >> E1_PIECE_LOG;       // pieces below this lie in front of everybody's window
+                if (ok_p > E1_NPIECE) ok_p = E1_NPIECE;
+                const uint32_t had = uni(atomicMax(lane == 0 ? &sh.pieces[par] : &sh.idle[lane], ok_p));
+                for (uint32_t pc = had; pc < ok_p; pc++) e1_dma_piece(sh, src, org, ts + E1_TILE, pc);
+            }
+            if (mode == 0 && si >= E1_PROBE_SLICES) {
+                mode = uni(__hip_atomic_load(&sh.hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) > E1_DENSE_HITS ? 2u : 1u;
+                *(lane == 0 ? &sh.mode : &sh.idle[lane]) = mode;
+            }
+            const uint32_t cs = ts + si * E1_SLICE;
+            const uint32_t ce = (cs + grab * E1_SLICE < te) ? cs + grab * E1_SLICE : te;
+            uint64_t* myrec = spec_t + si * E1_REC_PER_SLICE;
+            E1DBG(a_deq += clock64() - z0;)
+            uint32_t nrec = 0, anchor = cs;
+            uint32_t ip = uni(__hip_atomic_load(&sh.cov, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));      // (a match published by another wave may reach into this slice, or over it)
+            if (ip < cs) ip = cs;
+            if (!(g.e1_solo & 2u) && blen >= MFLIMIT + 1 && ip + MINMATCH <= te && ip + MFLIMIT <= bend && ip < ce) {
+                uint32_t last_start = ce - 1;
+                if (te - MINMATCH < last_start) last_start = te - MINMATCH;
+                if (bend - MFLIMIT < last_start) last_start = bend - MFLIMIT;
+                const uint32_t floor_b = ip;                               // backward extension stops here
+                uint32_t step = 1, two = opener ? 0u : 1u;
+                E1DBG(uint32_t it = 0;)
+                while (ip <= last_start) {
+                    E1DBG(if (++it > 100000) { if (lane == 0) { atomicAdd((unsigned long long*)&scratch[E1_DBG_AT + 1], 1ull); scratch[E1_DBG_AT + 8] = ((uint64_t)ip << 32) | last_start; scratch[E1_DBG_AT + 9] = ((uint64_t)step << 32) | si; } break; })
+                    E1DBG(const unsigned long long z1 = clock64(); n_step++;)
+                    // Two steps at once - A, and B = the step after A if A finds nothing - so that their LDS round trips overlap.
+                    // (B reads the table before A's positions go in: like two positions of one step, they do not see each other.  The tile's
+                    // first step goes alone: where the data repeats with a short period, what it indexes is what the second step finds.)
+                    const uint32_t ipB = ip + WAVE * step, stepB = step + 1;
+                    const uint32_t pA = ip + lane * step, pB = ipB + lane * stepB;
+                    const bool actA = pA <= last_start, actB = two && pB <= last_start;
+                    const uint32_t vA = e1_ld32(sh.ring, pA), vB = e1_ld32(sh.ring, pB);      // (idle lanes read on in the ring: harmless)
+                    const uint32_t hvA = e1_mix(vA), hA = e1_slot(hvA), tgA = e1_tag(hvA);
+                    const uint32_t hvB = e1_mix(vB), hB = e1_slot(hvB), tgB = e1_tag(hvB);
+                    const uint32_t eA = sh.table[hA], etA = sh.tags[hA], eB = sh.table[hB], etB = sh.tags[hB];
+                    const uint32_t distA = (pA - eA) & 0xFFFFu, distB = (pB - eB) & 0xFFFFu;
+                    // 21 hash bits agree: worth a look at the bytes (in incompressible input one step in five gets that far)
+                    const bool okA = actA && etA == tgA && distA != 0 && distA <= pA - low;
+                    const bool okB = actB && etB == tgB && distB != 0 && distB <= pB - low;
+                    // The table is shared with waves further ahead, and a run of one byte (or of a short period) is a single hot slot that
+                    // always holds a position of whoever is furthest ahead.  Such runs are found without it: the lane below probes the
+                    // position `step` bytes back, and if its four bytes are mine, that is a match.
+                    const uint32_t nbA = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vA, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+                    const uint32_t nbB = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vB, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+                    uint64_t m = __ballot(okA);
+                    if (m) m = __ballot(okA && e1_ld32(sh.ring, pA - distA) == vA);
+                    uint64_t mr = __ballot(actA && (lane & 15u) != 0 && nbA == vA) & ~m;
+                    m |= mr;
+                    bool inB = false;
+                    if (!m) {
+                        if (actA) { sh.table[hA] = (uint16_t)pA; sh.tags[hA] = (uint8_t)tgA; }
+                        m = __ballot(okB);
+                        if (m) m = __ballot(okB && e1_ld32(sh.ring, pB - distB) == vB);
+                        mr = __ballot(actB && (lane & 15u) != 0 && nbB == vB) & ~m;
+                        m |= mr;
+                        inB = true;
+                    }
+                    // the greedy parse indexes the positions up to the match it takes, not the ones it jumps over: those come up
+                    // again in the next step and would find themselves in the table instead of their candidates
+                    const uint32_t L = m ? (uint32_t)__builtin_ctzll(m) : WAVE;
+                    if (!inB) { if (actA && lane <= L) { sh.table[hA] = (uint16_t)pA; sh.tags[hA] = (uint8_t)tgA; } }
+                    else      { if (actB && lane <= L) { sh.table[hB] = (uint16_t)pB; sh.tags[hB] = (uint8_t)tgB; } }
+                    E1DBG(const unsigned long long z2 = clock64(); a_probe += z2 - z1;)
+                    if (!m) { ip = two ? ipB + WAVE * stepB : ipB; step += 1 + two; two = 1; continue; }
+                    E1DBG(n_hit++;)
+                    const uint32_t dsel = ((mr >> lane) & 1ull) ? (inB ? stepB : step) : (inB ? distB : distA);
+                    uint32_t mp = (uint32_t)__builtin_amdgcn_readlane(inB ? pB : pA, L);
+                    const uint32_t d = (uint32_t)__builtin_amdgcn_readlane(dsel, L);
+                    // backwards: up to the last match end (or where this slice began) and the lowest position a match may read
+                    uint32_t room = mp - (anchor > floor_b ? anchor : floor_b); if (mp - d - low < room) room = mp - d - low;
+                    uint32_t nb = 0;
+                    E1DBG(uint32_t itb = 0;)
+                    for (;;) {
+                        E1DBG(if (++itb > 100000) { if (lane == 0) { atomicAdd((unsigned long long*)&scratch[E1_DBG_AT + 2], 1ull); scratch[E1_DBG_AT + 10] = ((uint64_t)room << 32) | nb; } break; })
+                        const uint32_t kb = nb + lane + 1;
+                        const bool eq = kb <= room && sh.ring[(mp - kb) & E1_RMASK] == sh.ring[(mp - d - kb) & E1_RMASK];
+                        const uint64_t ne = __ballot(!eq);
+                        const uint32_t n1 = ne ? (uint32_t)__builtin_ctzll(ne) : WAVE;
+                        nb += n1;
+                        if (n1 < WAVE) break;
+                    }
+                    // forwards: 512 bytes per round
+                    uint32_t fw = 0;
+                    E1DBG(uint32_t itf = 0;)
+                    for (;;) {
+                        E1DBG(if (++itf > 100000) { if (lane == 0) { atomicAdd((unsigned long long*)&scratch[E1_DBG_AT + 3], 1ull); scratch[E1_DBG_AT + 11] = ((uint64_t)mp << 32) | fw; scratch[E1_DBG_AT + 12] = ((uint64_t)end_lim << 32) | d; } break; })
+                        const uint32_t a0 = mp + fw + lane * 8;
+                        uint32_t g0 = 0;
+                        if (a0 < end_lim) {
+                            const uint64_t x = e1_ld64(sh.ring, a0) ^ e1_ld64(sh.ring, a0 - d);
+                            g0 = x ? (uint32_t)(__builtin_ctzll(x) >> 3) : 8u;
+                            const uint32_t r = end_lim - a0; if (g0 > r) g0 = r;
+                        }
+                        const uint64_t stop = __ballot(g0 < 8);
+                        if (stop) { const uint32_t f = (uint32_t)__builtin_ctzll(stop); fw += f * 8 + (uint32_t)__builtin_amdgcn_readlane(g0, f); break; }
+                        fw += WAVE * 8;
+                    }
+                    mp -= nb;
+                    const uint32_t mlen = nb + fw;
+                    myrec[nrec] = pack_rec(mp - anchor, mlen, d);              // (every lane stores the same 8 bytes)
+                    nrec++;
+                    anchor = ip = mp + mlen;
+                    step = 1; two = 1;
+                    atomicMax(lane == 0 ? &sh.cov : &sh.idle[lane], ip);
+                    // like the CPU encoder, also index ip - 2
+                    E1DBG(a_hit += clock64() - z2;)
+                    if (ip >= low + 2 && ip + 2 <= te) { const uint32_t q2 = ip - 2, hv2 = e1_mix(e1_ld32(sh.ring, q2)); *(lane == 0 ? &sh.table[e1_slot(hv2)] : (uint16_t*)&sh.idle[lane]) = (uint16_t)q2; *(lane == 0 ? &sh.tags[e1_slot(hv2)] : (uint8_t*)&sh.idle[lane]) = (uint8_t)e1_tag(hv2); }
+                }
+            }
+            // (lane k for slice si + k; the other lanes store to words of their own: no branch, no 64 stores to one address)
+            const bool mine_s = lane < grab && si + lane < nslice;
+            *(mine_s ? &sh.s_end[par][si + lane] : &sh.idle[lane]) = (lane == 0 && nrec) ? anchor : 0u;
+            *(mine_s ? &sh.s_n[par][si + lane] : (uint8_t*)&sh.idle[lane]) = (uint8_t)(lane == 0 ? nrec : 0u);
+            if (mode == 0) atomicAdd(lane == 0 ? &sh.hits : &sh.idle[lane], nrec);
+            if (opener) *(lane == 0 ? &sh.first : &sh.idle[lane]) = 1u;
+        }
+        E1DBG(const unsigned long long q2 = clock64();)
+        __builtin_amdgcn_s_waitcnt(0);                                   // my slice lists are written
+        __syncthreads();                                                 // every slice is done: nobody reads the ring's older half any more
+        E1DBG(const unsigned long long q3 = clock64();)
+        pend = true; p_c = c; p_par = par; p_ts = ts; p_te = te; p_bend = bend; p_ns = nslice;
+
+        // ---- what is left of the next tile into the ring; counters for it ----
+        if (tid == 0) { sh.cov = nts; sh.hits = 0; sh.first = 0; sh.next = 1; sh.pieces[par ^ 1u] = 0; }      // (slice 0 is the first wave's)
+        if (tid < 16) sh.cur[tid] = 0;
+        if (nlen) {
+            if (nlen_full) {
+                const uint32_t had = sh.pieces[par];
+                for (uint32_t pc = had + wave; pc < E1_NPIECE; pc += E1_WAVES) e1_dma_piece(sh, src, org, nts, pc);
+                // the ring's first bytes again behind its end
+                if ((nts & E1_RMASK) == 0 && tid >= 64 && tid < 68) ((uint32_t*)(sh.ring + E1_RING))[tid - 64] = *(const u32_ua*)(src + (org + nts + (tid - 64) * 4u));
+            } else e1_fill(sh, src, org, nts, nts + nlen, tid);          // a short last block's last tile
+        }
+        E1DBG(const unsigned long long q4 = clock64();)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // my part of the next tile has landed
+        E1DBG(const unsigned long long q5 = clock64();)
+        __syncthreads();
+        E1DBG(if (blockIdx.x == 0 && lane == 0) { unsigned long long* d = (unsigned long long*)&scratch[E1_DBG_AT + 16 + wave * 8]; d[0] += q1 - q0; d[1] += q2 - q1; d[2] += q3 - q2; d[3] += q4 - q3; d[4] += q5 - q4; d[5] += clock64() - q5; d[6] += 1; unsigned long long* f = (unsigned long long*)&scratch[E1_DBG_AT + 160 + wave * 6]; f[0] += a_deq; f[1] += a_probe; f[2] += a_hit; f[3] += n_deq; f[4] += n_step; f[5] += n_hit; })
+    }
+    if (pend && wave == E1_WAVES - 1) merge(p_c, p_par, p_ts, p_te, p_bend, p_ns);
+}
+
+// ------------------------------- pass S --------------------------------------------------------
+// Three launches: per block on a wave (chunks in the lanes, carries and offsets by prefix sums), the scan over the blocks on
+// one workgroup, the per-chunk fix-up on a thread per chunk.
 
 template <int WAVES_PER_WG>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_layout_blocks(EncGeom g, ChunkInfo* __restrict__ info, BlockOut* __restrict__ table,
@@ -690,75 +805,9 @@ __device__ __forceinline__ void emit_len_ext(uint8_t* p, uint32_t v /* value min
     if (lane == 0) p[n255] = (uint8_t)(v - n255 * 255);
 }
 
-template <int WAVES_PER_WG>
-__global__ __launch_bounds__(64 * WAVES_PER_WG) void k_emit(const uint8_t* __restrict__ src, EncGeom g,
-                                                            const ChunkInfo* __restrict__ info, const uint64_t* __restrict__ recs,
-                                                            uint8_t* __restrict__ dst, const BlockOut* __restrict__ table, void* __restrict__ ix)
-{
-    const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t chunk = uni(blockIdx.x * WAVES_PER_WG + wave);
-    if (chunk >= g.n_chunks) return;
-    const uint32_t blk = chunk / g.chunks_per_block, cib = chunk % g.chunks_per_block;
-    const uint64_t bstart = g.first_off + (uint64_t)blk * g.block_size;
-    const uint64_t bend_abs = (bstart + g.block_size < g.src_size) ? bstart + g.block_size : g.src_size;
-    const uint64_t cs_abs = bstart + (uint64_t)cib * g.chunk_size;
-    if (cs_abs >= bend_abs) return;
-    const uint64_t ce_abs = (cs_abs + g.chunk_size < bend_abs) ? cs_abs + g.chunk_size : bend_abs;
-    const ChunkInfo ci = info[chunk];
-    if (ci.flags & 4u) return;
-    uint8_t* o = dst + ci.out_off;
-    if (ci.flags & 1u) {                                   // stored block: this chunk's slice of it
-        const uint64_t n = ce_abs - cs_abs;
-        for (uint64_t off = 0; off < n; off += 1u << 20) {
-            const uint32_t m = (uint32_t)((n - off < (1u << 20)) ? n - off : (1u << 20));
-            wave_copy_disjoint(o + off, src + cs_abs + off, m);
-        }
-        return;
-    }
-    const uint64_t* rec = recs + (uint64_t)chunk * g.max_rec_per_chunk;
-    const uint8_t* lp = src + (cs_abs - ci.carry_in);       // start of the pending literal run
-    // sequence index: an entry every IX_STRIDE records
-    IxEntry* ent = nullptr; uint32_t ent_seq0 = 0, ent_last = 0; const uint8_t* pay0 = nullptr;
-    if (ix && ((const IxHeader*)ix)->magic == IX_MAGIC && ci.nrec) {
-        const IxChunk ck = ix_chunks(ix, g.n_blocks)[chunk];
-        ent = ix_entries_w(ix, g.n_blocks, g.chunks_per_block) + ix_blocks(ix)[blk].entry_base + (ck.ent_off & 0x7FFFFFFFu);
-        ent_seq0 = ck.seq_off; ent_last = ck.ent_off >> 31;
-        pay0 = dst + table[blk].src_off;
-    }
-    for (uint32_t r = 0; r < ci.nrec; r++) {
-        if (ent && (r % IX_STRIDE) == 0 && lane == 0) {
-            uint32_t ns = ci.nrec - r < IX_STRIDE ? ci.nrec - r : IX_STRIDE;
-            if (ent_last && r + IX_STRIDE >= ci.nrec) ns += 1;                 // the block's final sequence rides on its last entry
-            ent[r / IX_STRIDE] = IxEntry{(uint32_t)(o - pay0), (uint32_t)(lp - (src + bstart)), ent_seq0 + r, ns | (blk << 8)};
-        }
-        const uint64_t x = rec[r];
-        uint32_t lit = (uint32_t)(x & 0xFFFFFFu);
-        const uint32_t mlen = (uint32_t)((x >> 24) & 0xFFFFFFu), off = (uint32_t)(x >> 48);
-        if (r == 0) lit += ci.carry_in;
-        const uint32_t mcode = mlen - MINMATCH;
-        if (lane == 0) *o = (uint8_t)(((lit < 15 ? lit : 15) << 4) | (mcode < 15 ? mcode : 15));
-        o += 1;
-        if (lit >= 15) { emit_len_ext(o, lit - 15); o += len_ext_bytes(lit); }
-        wave_copy_disjoint(o, lp, lit);
-        o += lit;
-        if (lane == 0) { o[0] = (uint8_t)off; o[1] = (uint8_t)(off >> 8); }
-        o += 2;
-        if (mcode >= 15) { emit_len_ext(o, mcode - 15); o += len_ext_bytes(mcode); }
-        lp += lit + mlen;
-    }
-    if (ci.flags & 2u) {                                   // last chunk: final literal-only sequence
-        const uint32_t lit = ci.nrec ? ci.tail_lit : ci.tail_lit + ci.carry_in;
-        if (lane == 0) *o = (uint8_t)((lit < 15 ? lit : 15) << 4);
-        o += 1;
-        if (lit >= 15) { emit_len_ext(o, lit - 15); o += len_ext_bytes(lit); }
-        wave_copy_disjoint(o, lp, lit);
-    }
-}
-
-
 // ------------------------------- pass E2, 64 records at a time ----------------------------------
-// Same bytes as k_emit.  There a wave walks its chunk's records one by one - token, length bytes, literal copy, offset - with
-// one copy in flight and ~90 scalar instructions per record.  Here 64 records sit in the lanes: two prefix sums give every
+// Walking a chunk's records one by one - token, length bytes, literal copy, offset - is one copy in flight and ~90 scalar
+// instructions per record.  Here 64 records sit in the lanes: two prefix sums give every
 // record its place in the payload and its literals' place in the input, each lane writes its own token / length bytes /
 // offset, and the literal runs of all 64 are copied by the lane-level gather of decode_fused.cuh (16-byte units found by
 // binary search over a prefix table in LDS, two rounds in flight), runs under 16 bytes with a lane per byte.

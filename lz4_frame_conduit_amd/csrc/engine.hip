@@ -73,8 +73,7 @@ int selected_device()
 
 uint32_t pick_chunk_size(uint32_t block_size)
 {
-    uint32_t c = 64u << 10;          // (with pass S spread over the machine, 64 KiB chunks beat 128 KiB: E1 4.86 vs 4.99 ms, ratio -0.05 %)
-    if (const char* s = getenv("LZ4F_MI355X_CHUNK")) { uint32_t v = (uint32_t)atoi(s); if (v >= 4096 && (v & (v - 1)) == 0) c = v; }
+    const uint32_t c = 64u << 10;    // pass E1's tile (E1_TILE): what one workgroup searches at a time, and the unit of passes S and E2
     return block_size < c ? block_size : c;
 }
 
@@ -118,7 +117,7 @@ lz4f_mi355x_engine::~lz4f_mi355x_engine()
     (void)hipSetDevice(device);
     (void)hipStreamSynchronize((hipStream_t)stream);
     desc.release(); seqcnt.release(); selfix.release(); selfcnt.release(); postab.release(); pdbuf.release();
-    info.release(); recs.release(); table.release(); blk_bytes.release(); res.release(); bad.release();
+    info.release(); recs.release(); e1_scratch.release(); table.release(); blk_bytes.release(); res.release(); bad.release();
     d_in.release(); d_out.release();
     h_in.release(); h_out.release(); h_small.release();
     for (int i = 0; i < 20; i++) if (ev[i]) (void)hipEventDestroy((hipEvent_t)ev[i]);
@@ -176,8 +175,8 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     g.linked = j.linked; g.block_checksum = j.block_checksum;
     g.header_size = j.header_size; memcpy(g.header, j.header, j.header_size);
     g.max_rec_per_chunk = g.chunk_size / 4 + 1;
-    g.seed_stride = 4; g.seed_dense = 1024;
-    if (const char* sv = getenv("LZ4F_MI355X_SEED")) { unsigned a = 0, b = 0; if (sscanf(sv, "%u,%u", &a, &b) == 2 && a >= 1) { g.seed_stride = a; g.seed_dense = b; } }
+    g.seed_stride = 2;
+    if (const char* sv = getenv("LZ4F_MI355X_SEED")) { unsigned a = 0; if (sscanf(sv, "%u", &a) == 1 && a >= 1 && a <= 64) g.seed_stride = a; }
 
     if (info.ensure((size_t)(g.n_chunks + 1) * sizeof(ChunkInfo))) return make_err(LZ4F_ERROR_allocation_failed);
     if (recs.ensure((size_t)(g.n_chunks + 1) * g.max_rec_per_chunk * 8)) return make_err(LZ4F_ERROR_allocation_failed);
@@ -189,18 +188,31 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     for (int i = 0; i < 4; i++) ev_used[i] = false;
     if (g.n_chunks) {
         tick(0, false);
-        constexpr int WF = 1;       // 12 KiB of LDS per wave: one-wave workgroups pack 13 waves into a CU's 160 KiB, four-wave ones 12
-        hipLaunchKernelGGL((k_find_matches<WF>), dim3((g.n_chunks + WF - 1) / WF), dim3(64 * WF), 0, st, j.d_src, g,
-                           (ChunkInfo*)info.p, (uint64_t*)recs.p, (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr));
+        {
+            // a workgroup (one per CU: ~150 KiB of LDS) takes a run of consecutive 64 KiB tiles.  At most 1024 workgroups (each
+            // has its slice lists in `e1_scratch`), runs of at least 16 tiles where the input is big enough for 1024 of those
+            // (the history loaded in front of a run is then 1/16 of the input or less)
+            uint32_t run = (g.n_chunks + 1023) / 1024; if (run < 16) { run = g.n_chunks / 1024; run = run < 1 ? 1 : run > 16 ? 16 : run; }
+            if (const char* rv = getenv("LZ4F_MI355X_E1_RUN")) { const int v = atoi(rv); if (v >= 1 && v <= 4096) run = (uint32_t)v; }
+            g.tiles_per_wg = run;
+            g.e1_solo = getenv("LZ4F_MI355X_E1_SOLO") ? (uint32_t)atoi(getenv("LZ4F_MI355X_E1_SOLO")) : 0u;
+            const uint32_t n_wg = (g.n_chunks + run - 1) / run;
+            if (e1_scratch.ensure((size_t)n_wg * 2 * E1_NSLICE * E1_REC_PER_SLICE * 8 + 2048)) return make_err(LZ4F_ERROR_allocation_failed);
+#ifdef E1_DEBUG
+            (void)hipMemsetAsync((uint8_t*)e1_scratch.p + (size_t)n_wg * 2 * E1_NSLICE * E1_REC_PER_SLICE * 8, 0, 2048, st);
+#endif
+            hipLaunchKernelGGL(k_find_matches, dim3(n_wg), dim3(64 * E1_WAVES), 0, st, j.d_src, g, (ChunkInfo*)info.p, (uint64_t*)recs.p, (uint64_t*)e1_scratch.p);
+            if (getenv("LZ4F_MI355X_E1_SYNC")) (void)hipStreamSynchronize(st);
+#ifdef E1_DEBUG
+            { unsigned long long d[256]; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(d, (uint8_t*)e1_scratch.p + (size_t)n_wg * 2 * E1_NSLICE * E1_REC_PER_SLICE * 8, 2048, hipMemcpyDeviceToHost) == hipSuccess) {
+                for (int w = 0; w < 16; w += 5) { unsigned long long* x = d + 16 + w * 8; if (x[6]) fprintf(stderr, "E1 wave %d: per tile cycles: merge %llu parse %llu waitB1 %llu dma-issue %llu dma-wait %llu waitB2 %llu (%llu tiles)\n", w, x[0]/x[6], x[1]/x[6], x[2]/x[6], x[3]/x[6], x[4]/x[6], x[5]/x[6], x[6]); unsigned long long* f = d + 160 + w * 6; fprintf(stderr, "   parse: dequeue %llu cycles x %llu, probe step %llu cycles x %llu, hit %llu cycles x %llu (per tile)\n", f[3] ? f[0]/f[3] : 0, f[3]/x[6], f[4] ? f[1]/f[4] : 0, f[4]/x[6], f[5] ? f[2]/f[5] : 0, f[5]/x[6]); }
+                fprintf(stderr, "E1 debug: bounds hit: dequeue %llu, probe %llu, backward %llu, forward %llu; probe ip/last %llx step/slice %llx; back room/nb %llx; fwd mp/fw %llx end_lim/d %llx\n", d[0], d[1], d[2], d[3], d[8], d[9], d[10], d[11], d[12]); } }
+#endif
+        }
         tick(0, true);
     }
     tick(1, false);
-    if (getenv("LZ4F_MI355X_LAYOUT_SERIAL")) {                                    // everything from one workgroup (same results)
-        hipLaunchKernelGGL(k_layout, dim3(1), dim3(1024), 0, st, g, (ChunkInfo*)info.p, (BlockOut*)d_table, (uint32_t*)blk_bytes.p,
-                           d_dst, dst_cap, (ResultRec*)d_res);
-        if (d_index)
-            hipLaunchKernelGGL(k_build_index, dim3(1), dim3(1024), 0, st, g, (const ChunkInfo*)info.p, (const BlockOut*)d_table, (const ResultRec*)d_res, d_index, (uint64_t)index_cap, 0u);
-    } else {
+    {
         if (g.n_blocks) hipLaunchKernelGGL((k_layout_blocks<W>), dim3((g.n_blocks + W - 1) / W), dim3(64 * W), 0, st, g, (ChunkInfo*)info.p, (BlockOut*)d_table, (uint32_t*)blk_bytes.p);
         hipLaunchKernelGGL(k_layout_scan, dim3(1), dim3(1024), 0, st, g, (BlockOut*)d_table, (const uint32_t*)blk_bytes.p, d_dst, dst_cap, (ResultRec*)d_res);
         if (g.n_chunks) hipLaunchKernelGGL(k_layout_chunks, dim3((g.n_chunks + 255) / 256), dim3(256), 0, st, g, (ChunkInfo*)info.p, (const BlockOut*)d_table, d_dst, (const ResultRec*)d_res);
@@ -212,12 +224,8 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     tick(1, true);
     if (g.n_chunks) {
         tick(2, false);
-        if (getenv("LZ4F_MI355X_EMIT_SERIAL"))                                  // the record-at-a-time kernel (same bytes)
-            hipLaunchKernelGGL((k_emit<W>), dim3((g.n_chunks + W - 1) / W), dim3(64 * W), 0, st, j.d_src, g, (const ChunkInfo*)info.p,
-                               (const uint64_t*)recs.p, d_dst, (const BlockOut*)d_table, d_index);
-        else
-            hipLaunchKernelGGL((k_emit_gather<W>), dim3((g.n_chunks + W - 1) / W), dim3(64 * W), 0, st, j.d_src, g, (const ChunkInfo*)info.p,
-                               (const uint64_t*)recs.p, d_dst, (const BlockOut*)d_table, d_index);
+        hipLaunchKernelGGL((k_emit_gather<W>), dim3((g.n_chunks + W - 1) / W), dim3(64 * W), 0, st, j.d_src, g, (const ChunkInfo*)info.p,
+                           (const uint64_t*)recs.p, d_dst, (const BlockOut*)d_table, d_index);
         tick(2, true);
         if (j.block_checksum) {
             tick(3, false);

@@ -564,7 +564,12 @@ def test_indexed_decode_same_bytes_as_generic(L):
             plain = torch.empty_like(frame)
             eng.compress_async(src, plain, p, eng.new_table(nb))
             rp = eng.result()
-            assert rp.size == r.size and torch.equal(plain[:r.size], frame[:r.size]), (name, kw)      # the frame does not depend on the index
+            # (pass E1's waves race for hash-table slots, so two compressions of one input may choose different - equally valid - matches:
+            # the frames are compared through what they decode to; sizes are held against liblz4's in the ratio tests)
+            chk = torch.zeros_like(src)
+            eng.decompress_frame_async(plain, int(rp.size), chk)
+            rc = eng.result()
+            assert rc.size == src.numel() and torch.equal(chk, src), (name, kw)
             hd = index[:32].cpu().numpy().view(np.uint32)
             used += int(hd[0] == 0x3258494C)
             back = torch.zeros_like(src)
