@@ -155,6 +155,10 @@ LZ4F_MI355X_API int lz4f_mi355x_device_count(void);
 /* which device the calling thread's contexts and engines are created on (default: 0, or the
  * LZ4F_MI355X_DEVICE environment variable) */
 LZ4F_MI355X_API size_t lz4f_mi355x_set_device(int device);
+/* The host-pointer entry points (the twelve LZ4F_* functions, compressFrame / decompressFrame, the conduits) borrow an engine
+ * - a HIP stream, pinned staging, device workspace - from a process-wide pool for the duration of a call and give it back;
+ * nothing is owned by a thread.  This frees the engines that are idle right now (the pool refills on demand). */
+LZ4F_MI355X_API void lz4f_mi355x_release_engines(void);
 
 /* Worst-case size of a whole frame for srcSize bytes (header + blocks + EndMark + checksum). */
 LZ4F_MI355X_API size_t lz4f_mi355x_compressFrameBound(size_t srcSize, const LZ4F_preferences_t* prefs);

@@ -61,6 +61,7 @@ _SIGS = {
     "lz4f_mi355x_decompress": (c_size_t, [c_void_p, c_void_p, ctypes.POINTER(c_size_t), c_void_p, ctypes.POINTER(c_size_t), c_void_p]),
     # PART 2
     "lz4f_mi355x_last_error": (ctypes.c_char_p, []), "lz4f_mi355x_device_count": (ctypes.c_int, []), "lz4f_mi355x_set_device": (c_size_t, [ctypes.c_int]),
+    "lz4f_mi355x_release_engines": (None, []),
     "lz4f_mi355x_compressFrameBound": (c_size_t, [c_size_t, PP]),
     "lz4f_mi355x_compressFrame": (c_size_t, [c_void_p, c_size_t, c_void_p, c_size_t, PP]),
     "lz4f_mi355x_decompressFrame": (c_size_t, [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]),

@@ -7,7 +7,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <thread>
+#include <vector>
 
 #include "engine.hpp"
 #include "frame_dev.cuh"
@@ -22,7 +24,6 @@ namespace lz4f {
 
 static thread_local char t_err[512] = "";
 static thread_local int t_device = -1;
-static thread_local lz4f_mi355x_engine* t_engine = nullptr;
 
 void set_last_error(const char* fmt, ...)
 {
@@ -100,15 +101,44 @@ size_t new_engine(lz4f_mi355x_engine** out, int device, void* stream, bool borro
     return 0;
 }
 
-size_t thread_engine(lz4f_mi355x_engine** out)
-{
-    if (!t_engine) {
-        size_t r = new_engine(&t_engine, selected_device(), nullptr, false);
-        if (is_err(r)) { t_engine = nullptr; return r; }
+// ---- engines for the host-pointer entry points: a pool per process, not an engine per thread ----
+// (A Haskell host's safe FFI calls land on arbitrary OS threads: engines owned by threads would be leaked with them - stream,
+// pinned staging, device workspace.  A call borrows an idle engine of the wanted device, or makes one, and gives it back;
+// lz4f_mi355x_release_engines() frees the idle ones, and so does the library's unload.)
+namespace {
+struct EnginePool {
+    std::mutex mu;
+    std::vector<lz4f_mi355x_engine*> idle;
+    ~EnginePool() { drain(); }
+    void drain()
+    {
+        std::vector<lz4f_mi355x_engine*> v;
+        { std::lock_guard<std::mutex> g(mu); v.swap(idle); }
+        for (auto* e : v) delete e;
     }
-    *out = t_engine;
-    return 0;
+};
+EnginePool& pool() { static EnginePool p; return p; }
+}  // namespace
+
+size_t acquire_engine(lz4f_mi355x_engine** out, int device)
+{
+    if (device < 0) device = selected_device();
+    {
+        EnginePool& p = pool();
+        std::lock_guard<std::mutex> g(p.mu);
+        for (size_t i = 0; i < p.idle.size(); i++)
+            if (p.idle[i]->device == device) { *out = p.idle[i]; p.idle.erase(p.idle.begin() + i); return 0; }
+    }
+    return new_engine(out, device, nullptr, false);
 }
+void release_engine(lz4f_mi355x_engine* e)
+{
+    if (!e) return;
+    EnginePool& p = pool();
+    std::lock_guard<std::mutex> g(p.mu);
+    p.idle.push_back(e);
+}
+void release_idle_engines() { pool().drain(); }
 
 }  // namespace lz4f
 
@@ -246,6 +276,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
     if (bad.ensure(64)) return make_err(LZ4F_ERROR_allocation_failed);
     BlockOut* tbl;
     uint32_t n_max;
+    for (int i = 4; i < 10; i++) ev_used[i] = false;
     if (j.d_table || j.table_in_place) {
         // caller-supplied table: work on a copy (decode overwrites dst_size)
         n_max = j.n_blocks;
@@ -263,7 +294,6 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         tick(4, true);
     }
     HIP_TRY(hipMemsetAsync(bad.p, 0xFF, 4, st));
-    for (int i = 4; i < 10; i++) ev_used[i] = false;
     constexpr int W = 4;
     const uint32_t grid = j.linked ? 1u : (n_max + W - 1) / W;
     if (n_max) {
@@ -707,7 +737,6 @@ size_t lz4f_mi355x_set_device(int device)
 {
     int n = lz4f_mi355x_device_count();
     if (device < 0 || device >= n) { set_last_error("device %d out of range (%d devices)", device, n); return make_err(LZ4F_ERROR_GENERIC); }
-    if (lz4f::t_engine && lz4f::t_engine->device != device) { delete lz4f::t_engine; lz4f::t_engine = nullptr; }
     lz4f::t_device = device;
     return 0;
 }
@@ -718,6 +747,7 @@ size_t lz4f_mi355x_engine_create(lz4f_mi355x_engine** out, int device, void* hip
     return new_engine(out, device, hipStream, borrowStream != 0);
 }
 size_t lz4f_mi355x_engine_free(lz4f_mi355x_engine* e) { delete e; return 0; }
+void lz4f_mi355x_release_engines(void) { lz4f::release_idle_engines(); }
 void* lz4f_mi355x_engine_stream(lz4f_mi355x_engine* e) { return e ? e->stream : nullptr; }
 
 size_t lz4f_mi355x_engine_set_timing(lz4f_mi355x_engine* e, int enable)

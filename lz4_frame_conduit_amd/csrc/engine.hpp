@@ -111,8 +111,17 @@ private:
 };
 
 namespace lz4f {
-// engine bound to the calling thread's selected device; created on first use
-size_t thread_engine(lz4f_mi355x_engine** out);
+// an engine for one host-pointer call: borrowed from the process-wide pool (made on first use), given back by the lease.
+// device < 0: the calling thread's selected device
+size_t acquire_engine(lz4f_mi355x_engine** out, int device = -1);
+void   release_engine(lz4f_mi355x_engine* e);
+void   release_idle_engines();
+struct EngineLease {
+    lz4f_mi355x_engine* e = nullptr;
+    size_t get(int device = -1) { return acquire_engine(&e, device); }
+    ~EngineLease() { release_engine(e); }
+    lz4f_mi355x_engine* operator->() const { return e; }
+};
 size_t new_engine(lz4f_mi355x_engine** out, int device, void* stream, bool borrow);
 int    selected_device();
 uint32_t pick_chunk_size(uint32_t block_size);

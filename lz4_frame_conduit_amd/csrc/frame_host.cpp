@@ -175,8 +175,8 @@ static void push_history(LZ4F_cctx_s* c, const uint8_t* p, size_t n)
 // encode `n` bytes (whole blocks, the last may be short) -> appended to dst; returns bytes written or error
 static size_t encode_blocks(LZ4F_cctx_s* c, uint8_t* dst, size_t cap, const uint8_t* src, size_t n)
 {
-    lz4f_mi355x_engine* eng;
-    size_t r = thread_engine(&eng);
+    EngineLease eng;
+    size_t r = eng.get();
     if (is_err(r)) return r;
     size_t written = 0;
     r = eng->compress_blocks_host(src, n, c->hist.data(), c->hist.size(), (uint32_t)c->block_size,
@@ -551,8 +551,8 @@ size_t LZ4F_decompress(LZ4F_dctx* d, void* dstBuffer, size_t* dstSizePtr, const 
                 if (bck) csz -= 4;
                 const bool direct = (size_t)(dstEnd - dp) >= d->max_block;
                 uint8_t* out = direct ? dp : d->tmp_out.data();
-                lz4f_mi355x_engine* eng;
-                size_t r = thread_engine(&eng);
+                EngineLease eng;
+                size_t r = eng.get();
                 if (is_err(r)) return r;
                 uint32_t got = 0;
                 r = eng->decompress_block_host(selected, (uint32_t)csz, bck, d->hist.data(), d->hist.size(), out, (uint32_t)d->max_block,
@@ -710,8 +710,8 @@ size_t lz4f_mi355x_decompressFrame(void* dst, size_t dstCapacity, const void* sr
     ParsedHeader ph;
     size_t hs = parse_frame_header(s, srcSize, &ph);
     if (is_err(hs)) return hs;
-    lz4f_mi355x_engine* eng;
-    size_t r = thread_engine(&eng);
+    EngineLease eng;
+    size_t r = eng.get();
     if (is_err(r)) return r;
     size_t decoded = 0, consumed = 0;
     r = eng->decompress_frame_host(s, srcSize, ph, (uint8_t*)dst, dstCapacity, &decoded, &consumed);
