@@ -147,7 +147,7 @@ lz4f_mi355x_engine::~lz4f_mi355x_engine()
     (void)hipSetDevice(device);
     (void)hipStreamSynchronize((hipStream_t)stream);
     desc.release(); seqcnt.release(); selfix.release(); selfcnt.release(); postab.release(); pdbuf.release();
-    info.release(); recs.release(); e1_scratch.release(); table.release(); blk_bytes.release(); res.release(); bad.release();
+    info.release(); recs.release(); e1_scratch.release(); walkbuf.release(); table.release(); blk_bytes.release(); res.release(); bad.release();
     d_in.release(); d_out.release();
     h_in.release(); h_out.release(); h_small.release();
     for (int i = 0; i < 20; i++) if (ev[i]) (void)hipEventDestroy((hipEvent_t)ev[i]);
@@ -290,7 +290,33 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         if (table.ensure((size_t)(n_max + 1) * sizeof(BlockOut))) return make_err(LZ4F_ERROR_allocation_failed);
         tbl = (BlockOut*)table.p;
         tick(4, false);
-        hipLaunchKernelGGL(k_walk_frame, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, j.dst_cap, tbl, n_max, (ResultRec*)d_res);
+        // frames of many small blocks: the size words are found in parallel (frame_dev.cuh); k_walk_frame behind it returns at
+        // once when that has delivered, and walks the list itself otherwise (big blocks: a few hundred hops, and one in 2^9
+        // byte positions would be a candidate)
+        const uint32_t* walked = nullptr;
+        if (j.block_size <= (256u << 10) && j.frame_cap >= (1u << 20) && !getenv("LZ4F_MI355X_SERIAL_WALK")) {
+            const uint32_t n_chunks = (uint32_t)((j.frame_cap + WK_CHUNK - 1) / WK_CHUNK);
+            const size_t list_cap = (size_t)n_max + 1024;
+            const size_t at_chunks = 256, at_list = at_chunks + (size_t)n_chunks * sizeof(WalkChunk), at_list2 = at_list + list_cap * 8, at_mark = at_list2 + list_cap * 8;
+            if (walkbuf.ensure(at_mark + list_cap * 4)) return make_err(LZ4F_ERROR_allocation_failed);
+            WalkState* ws = (WalkState*)walkbuf.p;
+            WalkChunk* ch = (WalkChunk*)((uint8_t*)walkbuf.p + at_chunks);
+            uint64_t* list = (uint64_t*)((uint8_t*)walkbuf.p + at_list);
+            uint64_t* list2 = (uint64_t*)((uint8_t*)walkbuf.p + at_list2);
+            uint32_t* mark = (uint32_t*)((uint8_t*)walkbuf.p + at_mark);
+            const uint32_t lgrid = std::min<uint32_t>((uint32_t)((list_cap + 255) / 256), 4096u);
+            HIP_TRY(hipMemsetAsync(mark, 0, list_cap * 4, st));
+            hipLaunchKernelGGL(k_walk_head, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, ws);
+            hipLaunchKernelGGL(k_walk_cand, dim3(n_chunks), dim3(256), 0, st, j.d_frame, j.frame_cap, (const WalkState*)ws, ch);
+            hipLaunchKernelGGL(k_walk_order, dim3(1), dim3(1024), 0, st, ch, n_chunks, ws, list, (uint32_t)list_cap);
+            hipLaunchKernelGGL(k_walk_mark, dim3(lgrid), dim3(256), 0, st, j.d_frame, j.frame_cap, (const WalkState*)ws, (const uint64_t*)list, mark);
+            hipLaunchKernelGGL(k_walk_filter, dim3(1), dim3(1024), 0, st, ws, (const uint64_t*)list, (const uint32_t*)mark, list2);
+            hipLaunchKernelGGL(k_walk_link, dim3(lgrid), dim3(256), 0, st, j.d_frame, j.frame_cap, j.dst_cap, ws, (const uint64_t*)list2, tbl, n_max);
+            hipLaunchKernelGGL(k_walk_verdict, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, j.dst_cap, ws, (const uint64_t*)list2, n_max, (ResultRec*)d_res);
+            walked = &ws->done;
+            if (getenv("LZ4F_MI355X_PROF")) { WalkState h; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(&h, ws, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "parallel walk: done %u overflow %u candidates %u first_end %u first_break %u (header ok %u, hsize %u, block %u)\n", h.done, h.overflow, h.total, h.first_end, h.first_break, h.head_ok, h.hsize, h.bs); }
+        }
+        hipLaunchKernelGGL(k_walk_frame, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, j.dst_cap, tbl, n_max, (ResultRec*)d_res, walked);
         tick(4, true);
     }
     HIP_TRY(hipMemsetAsync(bad.p, 0xFF, 4, st));

@@ -53,6 +53,7 @@ struct lz4f_mi355x_engine {
     void* stream = nullptr;        // hipStream_t
     bool  own_stream = false;
     lz4f::DevBuf info, recs, table, blk_bytes, res, bad;   // workspace of the block kernels
+    lz4f::DevBuf walkbuf;                                  // frames without a block table: the parallel walk's candidates
     lz4f::DevBuf e1_scratch;                               // pass E1: per workgroup, the slice lists of the tile it is searching
     lz4f::DevBuf selfix, selfcnt;                          // linked frames without an index: the one made here, and its per-block counts
     lz4f::DevBuf pdbuf;                                    // dense frames by pointer doubling: a word per output byte

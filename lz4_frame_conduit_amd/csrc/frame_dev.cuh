@@ -120,9 +120,10 @@ __device__ uint32_t xxh32_small(const uint8_t* p, uint32_t len)   // len < 16: h
 // Single thread: the walk is a pointer chase (each size word's position depends on all earlier
 // ones).  Same validation order as the oracle's orc_decompress_frame.
 __global__ void k_walk_frame(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint64_t dst_cap,
-                             BlockOut* __restrict__ table, uint32_t table_cap, ResultRec* __restrict__ res)
+                             BlockOut* __restrict__ table, uint32_t table_cap, ResultRec* __restrict__ res, const uint32_t* __restrict__ walked = nullptr)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (walked && *walked) return;                                      // the parallel walk (below) has written table and result
     ResultRec r; r.size = 0; r.consumed = 0; r.status = ST_OK; r.n_blocks = 0; r.first_bad_block = 0xFFFFFFFFu; r.flags = 0;
     auto fail = [&](uint32_t st) { r.status = st; *res = r; };
     if (frame_cap < 7) return fail(12);                              // frameHeader_incomplete
@@ -171,6 +172,253 @@ __global__ void k_walk_frame(const uint8_t* __restrict__ frame, uint64_t frame_c
     if ((flg >> 2) & 1) { if (frame_cap - pos < 4) return fail(12); pos += 4; }   // content checksum: skipped, see header
     r.n_blocks = n; r.consumed = pos; r.size = content;             // size = declared content size until decode fills it
     *res = r;
+}
+
+// ------------------------------- frame walk, in parallel ----------------------------------------
+// The size words are a linked list: 16 384 dependent HBM reads (0.66 us each) for 1 GiB in 64 KiB blocks.  A block start has
+// a look, though: a word <= maxBlockSize (top bits clear) that leads to another such word, or to the EndMark.  So:
+//   k_walk_cand     every byte position of the frame is looked at once (a streaming read); a position whose word could be a
+//                   size word and whose chain survives WK_HOPS hops is a candidate; a workgroup keeps those of its 64 KiB
+//   k_walk_order    scan over the workgroups' counts -> the candidates in position order (one workgroup)
+//   k_walk_link     candidate i is a block start iff candidate i+1 is exactly where its size word points (or that is the
+//                   EndMark): if the list, from the first byte behind the header on, is such a chain, it IS the walk - the
+//                   block table is written from it; anything else (a false candidate in between, too many candidates)
+//                   leaves the frame to k_walk_frame, which then runs behind.
+// A wrong guess can therefore cost time, never change the table.
+constexpr uint32_t WK_CHUNK = 65536, WK_SLOTS = 30, WK_HOPS = 3;
+struct WalkState {                     // device scratch, zeroed per call
+    uint32_t done;                     // 1: the block table and the result record are final (k_walk_frame returns at once)
+    uint32_t overflow;                 // a workgroup had more candidates than slots / more candidates than table entries
+    uint32_t total;                    // candidates
+    uint32_t first_end;                // lowest candidate whose size word points at the EndMark
+    uint32_t first_break;              // lowest candidate whose successor is not where its size word points
+    uint32_t hsize, bs, bck, flg;      // from the header
+    uint32_t head_ok;
+    uint64_t content;
+};
+struct WalkChunk { uint32_t n; uint32_t off[WK_SLOTS]; uint32_t pad; };      // 128 bytes per 64 KiB of frame
+
+// header checks of k_walk_frame, shared (returns 0 and fills the fields, or the LZ4F error code)
+__device__ __forceinline__ uint32_t walk_header(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint32_t& hsize, uint32_t& bs, uint32_t& bck,
+                                                uint32_t& flg, uint64_t& content)
+{
+    if (frame_cap < 7) return 12;
+    const uint32_t magic = rd32_any(frame);
+    if (magic != 0x184D2204u) return 13;                              // (skippable frames: k_walk_frame)
+    flg = frame[4];
+    if ((flg >> 1) & 1) return 8;
+    if (((flg >> 6) & 3) != 1) return 6;
+    hsize = 7 + (((flg >> 3) & 1) ? 8 : 0) + ((flg & 1) ? 4 : 0);
+    if (frame_cap < hsize) return 12;
+    const uint32_t bd = frame[5];
+    const uint32_t bsid = (bd >> 4) & 7;
+    if ((bd >> 7) & 1) return 8;
+    if (bsid < 4) return ST_MAXBLOCK;
+    if (bd & 15) return 8;
+    if (((xxh32_small(frame + 4, hsize - 5) >> 8) & 0xFF) != frame[hsize - 1]) return 17;
+    bs = 1u << (8 + 2 * bsid);
+    bck = (flg >> 4) & 1;
+    content = 0;
+    if ((flg >> 3) & 1) content = (uint64_t)rd32_any(frame + 6) | ((uint64_t)rd32_any(frame + 10) << 32);
+    return 0;
+}
+
+__global__ void k_walk_head(const uint8_t* __restrict__ frame, uint64_t frame_cap, WalkState* __restrict__ ws)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t hsize = 0, bs = 0, bck = 0, flg = 0; uint64_t content = 0;
+    const uint32_t st = walk_header(frame, frame_cap, hsize, bs, bck, flg, content);
+    ws->done = 0; ws->overflow = 0; ws->total = 0; ws->first_end = 0xFFFFFFFFu; ws->first_break = 0xFFFFFFFFu;
+    ws->hsize = hsize; ws->bs = bs; ws->bck = bck; ws->flg = flg; ws->content = content;
+    ws->head_ok = st == 0 ? 1u : 0u;                                  // (a bad header: k_walk_frame gives the verdict)
+}
+
+// does the word at `pos` look like a size word whose block fits the frame?  -> position of the next word
+__device__ __forceinline__ bool walk_step(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint32_t bs, uint32_t bck, uint64_t pos, uint64_t& next, bool& end)
+{
+    if (frame_cap - pos < 4) return false;
+    const uint32_t w = *(const u32_ua*)(frame + pos);
+    end = w == 0;
+    if (end) { next = pos + 4; return true; }
+    const uint32_t csz = w & 0x7FFFFFFFu;
+    if (csz > bs) return false;
+    next = pos + 4 + csz + 4 * bck;
+    return next + 4 <= frame_cap;                                     // (there is at least an EndMark behind every block)
+}
+
+__global__ __launch_bounds__(256) void k_walk_cand(const uint8_t* __restrict__ frame, uint64_t frame_cap, const WalkState* __restrict__ ws,
+                                                   WalkChunk* __restrict__ chunks)
+{
+    __shared__ uint32_t s_n;
+    __shared__ uint32_t s_off[WK_SLOTS];
+    if (!ws->head_ok) return;
+    const uint32_t bs = ws->bs, bck = ws->bck, hsize = ws->hsize;
+    const uint64_t c0 = (uint64_t)blockIdx.x * WK_CHUNK;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    // a size word's upper bits: bit 31 may be set (stored block), the count is <= bs
+    const uint32_t hi_mask = ~((bs << 1) - 1u) & 0x7FFFFFFFu;       // bits that must be clear (bs itself is allowed: checked by walk_step)
+    for (uint32_t o = threadIdx.x * 16; o < WK_CHUNK; o += 256 * 16) {
+        const uint64_t p0 = c0 + o;
+        if (p0 + 4 > frame_cap) break;
+        // 20 bytes: my 16 positions' words (guarded at the frame's end)
+        uint32_t w[5] = {0, 0, 0, 0, 0};
+        if (p0 + 20 <= frame_cap) { const b16_ua t = *(const b16_ua*)(frame + p0); w[0] = t.a; w[1] = t.b; w[2] = t.c; w[3] = t.d; w[4] = *(const u32_ua*)(frame + p0 + 16); }
+        else { for (uint32_t k = 0; k < 20 && p0 + k < frame_cap; k++) w[k >> 2] |= (uint32_t)frame[p0 + k] << (8 * (k & 3)); }
+#pragma unroll
+        for (uint32_t i = 0; i < 16; i++) {
+            const uint32_t sh = (i & 3) * 8;
+            const uint32_t v = sh ? (w[i >> 2] >> sh) | (w[(i >> 2) + 1] << (32 - sh)) : w[i >> 2];
+            if ((v & hi_mask) != 0 || v == 0) continue;               // (the EndMark is an end, not a block)
+            const uint64_t p = p0 + i;
+            if (p < hsize || p + 4 > frame_cap) continue;
+            // a chain of WK_HOPS plausible words (or fewer, up to the EndMark) from here
+            uint64_t q = p, nx = 0; bool end = false, good = true;
+            for (uint32_t h = 0; h < WK_HOPS && good && !end; h++) { good = walk_step(frame, frame_cap, bs, bck, q, nx, end); if (h == 0 && end) good = false; q = nx; }
+            if (!good) continue;
+            const uint32_t at = atomicAdd(&s_n, 1u);
+            if (at < WK_SLOTS) s_off[at] = o + i;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) chunks[blockIdx.x].n = s_n;
+    if (threadIdx.x < WK_SLOTS && threadIdx.x < s_n) chunks[blockIdx.x].off[threadIdx.x] = s_off[threadIdx.x];
+}
+
+// one workgroup: exclusive scan over the chunks' counts, then every chunk's candidates, sorted, into the list
+__global__ __launch_bounds__(1024) void k_walk_order(WalkChunk* __restrict__ chunks, uint32_t n_chunks, WalkState* __restrict__ ws, uint64_t* __restrict__ list, uint32_t list_cap)
+{
+    __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_carry;
+    if (!ws->head_ok) return;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_chunks; base += 1024) {
+        const uint32_t c = base + t;
+        uint32_t n = c < n_chunks ? chunks[c].n : 0u;
+        if (n > WK_SLOTS) { ws->overflow = 1; n = 0; }
+        s_part[t] = n;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            const uint32_t a = t >= off ? s_part[t - off] : 0u;
+            __syncthreads();
+            s_part[t] += a;
+            __syncthreads();
+        }
+        const uint32_t at = s_carry + s_part[t] - n;
+        if (n) {
+            if (at + n > list_cap) ws->overflow = 1;
+            else {
+                uint32_t v[WK_SLOTS];
+                for (uint32_t i = 0; i < n; i++) v[i] = chunks[c].off[i];
+                for (uint32_t i = 1; i < n; i++) { const uint32_t x = v[i]; uint32_t j = i; while (j && v[j - 1] > x) { v[j] = v[j - 1]; j--; } v[j] = x; }
+                for (uint32_t i = 0; i < n; i++) list[at + i] = (uint64_t)c * WK_CHUNK + v[i];
+            }
+        }
+        __syncthreads();
+        if (t == 1023) s_carry += s_part[1023];
+        __syncthreads();
+    }
+    if (t == 0) ws->total = s_carry;
+}
+
+// A false candidate (a payload position whose bytes happen to chain) would break the list.  A true block start - but for the
+// first - is where another candidate's size word points, a false one practically never is: mark every candidate's
+// successor, then keep the first candidate and the marked ones.
+__global__ __launch_bounds__(256) void k_walk_mark(const uint8_t* __restrict__ frame, uint64_t frame_cap, const WalkState* __restrict__ ws,
+                                                   const uint64_t* __restrict__ list, uint32_t* __restrict__ mark)
+{
+    if (!ws->head_ok || ws->overflow) return;
+    const uint32_t total = ws->total, bs = ws->bs, bck = ws->bck;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        uint64_t nx = 0; bool end = false;
+        if (!walk_step(frame, frame_cap, bs, bck, list[i], nx, end) || end) continue;
+        uint32_t lo = i + 1, hi = total;                                // first entry >= nx (the list is sorted; the successor lies behind me)
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (list[mid] < nx) lo = mid + 1; else hi = mid; }
+        if (lo < total && list[lo] == nx) mark[lo] = 1;
+    }
+}
+// one workgroup: the kept candidates, in order, into list2 (ws->total becomes their number)
+__global__ __launch_bounds__(1024) void k_walk_filter(WalkState* __restrict__ ws, const uint64_t* __restrict__ list, const uint32_t* __restrict__ mark, uint64_t* __restrict__ list2)
+{
+    __shared__ uint32_t s_part[1024];
+    __shared__ uint32_t s_carry;
+    if (!ws->head_ok || ws->overflow) return;
+    const uint32_t t = threadIdx.x, total = ws->total;
+    if (t == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < total; base += 1024) {
+        const uint32_t i = base + t;
+        const uint32_t k = (i < total && (i == 0 || mark[i])) ? 1u : 0u;
+        s_part[t] = k;
+        __syncthreads();
+        for (uint32_t off = 1; off < 1024; off <<= 1) {
+            const uint32_t a = t >= off ? s_part[t - off] : 0u;
+            __syncthreads();
+            s_part[t] += a;
+            __syncthreads();
+        }
+        if (k) list2[s_carry + s_part[t] - 1] = list[i];
+        __syncthreads();
+        if (t == 1023) s_carry += s_part[1023];
+        __syncthreads();
+    }
+    if (t == 0) ws->total = s_carry;
+}
+
+__global__ __launch_bounds__(256) void k_walk_link(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint64_t dst_cap, WalkState* __restrict__ ws,
+                                                   const uint64_t* __restrict__ list, BlockOut* __restrict__ table, uint32_t table_cap)
+{
+    if (!ws->head_ok || ws->overflow) return;
+    const uint32_t total = ws->total;
+    const uint32_t bs = ws->bs, bck = ws->bck;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const uint64_t p = list[i];
+        uint64_t nx = 0; bool end = false;
+        bool ok = walk_step(frame, frame_cap, bs, bck, p, nx, end) && !end;
+        bool last = false;
+        if (ok) {
+            uint64_t n2 = 0; bool e2 = false;
+            const bool ok2 = walk_step(frame, frame_cap, bs, bck, nx, n2, e2);
+            last = ok2 && e2;                                         // my size word points at the EndMark
+            ok = last || (i + 1 < total && list[i + 1] == nx);
+        }
+        if (!ok) atomicMin(&ws->first_break, i);
+        else if (last) atomicMin(&ws->first_end, i);
+        if (ok && i < table_cap) {
+            const uint64_t out = (uint64_t)i * bs;
+            const uint32_t w = *(const u32_ua*)(frame + p);
+            table[i].src_off = p + 4; table[i].dst_off = out; table[i].word = w;
+            table[i].dst_size = out >= dst_cap ? 0u : (uint32_t)((dst_cap - out < bs) ? dst_cap - out : bs);
+        }
+    }
+}
+
+// the verdict: is the list, from the first byte behind the header to its first EndMark, one unbroken chain?
+__global__ void k_walk_verdict(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint64_t dst_cap, WalkState* __restrict__ ws,
+                               const uint64_t* __restrict__ list, uint32_t table_cap, ResultRec* __restrict__ res)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (!ws->head_ok || ws->overflow) return;
+    const uint32_t hsize = ws->hsize, bs = ws->bs, bck = ws->bck, flg = ws->flg;
+    uint32_t n = 0; uint64_t pos = hsize;
+    if (ws->total == 0 || list[0] != hsize) {
+        // no block at all?  then the EndMark follows the header
+        if (frame_cap - pos < 4 || *(const u32_ua*)(frame + pos) != 0) return;
+        pos += 4;
+    } else {
+        const uint32_t e = ws->first_end;
+        if (e == 0xFFFFFFFFu || ws->first_break <= e || e >= table_cap) return;
+        if ((uint64_t)e * bs >= dst_cap) return;                      // (no room: k_walk_frame says so)
+        n = e + 1;
+        const uint64_t p = list[e];
+        pos = p + 4 + (*(const u32_ua*)(frame + p) & 0x7FFFFFFFu) + 4 * bck + 4;      // behind the EndMark
+    }
+    if ((flg >> 2) & 1) { if (frame_cap - pos < 4) return; pos += 4; }               // content checksum
+    ResultRec r; r.size = ws->content; r.consumed = pos; r.status = ST_OK; r.n_blocks = n; r.first_bad_block = 0xFFFFFFFFu; r.flags = flg;
+    *res = r;
+    ws->done = 1;
 }
 
 // ------------------------------- block decode ---------------------------------------------------

@@ -746,3 +746,38 @@ def test_host_calls_across_staging_pieces(L):
             if n == (32 << 20) + 1:
                 ref, ref_used = oracle.decompress_frame(frame, cap=len(data) + 64)
                 assert ref_used == len(frame) and ref == data, (n, kw)
+
+
+@pytest.mark.gpu
+def test_parallel_walk_of_device_frames(L, monkeypatch):
+    """Device-resident frames without a block table (small blocks): the size words are found in parallel (k_walk_cand ...
+    k_walk_verdict) and must give the table the serial walk gives - also when the payload is full of bytes that look like
+    size words (stored blocks of small little-endian integers: false candidates, which are filtered out or send the frame
+    to the serial walk), with a block checksum behind every block, and with garbage behind the frame."""
+    import torch
+    from lz4_frame_conduit_amd.device import Engine
+    eng = Engine(0)
+    rng = np.random.default_rng(31)
+    ints = rng.integers(0, 40000, 3 << 20, dtype=np.uint32).view(np.uint8)                 # 12 MiB, every word a plausible size word
+    inputs = [("synth50", datagen.synth50(24 << 20, 5)), ("text", datagen.synth_text(20 << 20, 3)), ("small ints", ints),
+              ("structured", np.frombuffer(datagen.structured(17 << 20, 77), dtype=np.uint8).copy())]
+    for name, data in inputs:
+        for kw in (dict(bsid=4, indep=1), dict(bsid=4, indep=1, bck=1), dict(bsid=5, indep=1), dict(bsid=4, indep=0)):
+            ref = oracle.conduit_compress(data.tobytes(), oracle.mkprefs(**kw))              # == liblz4's frame
+            tail = rng.integers(0, 256, 4096, dtype=np.uint8).tobytes()
+            dev = torch.from_numpy(np.frombuffer(ref + tail, dtype=np.uint8).copy()).cuda()
+            src = torch.from_numpy(data).cuda()
+            results = []
+            for serial in (False, True):
+                if serial: monkeypatch.setenv("LZ4F_MI355X_SERIAL_WALK", "1")
+                else: monkeypatch.delenv("LZ4F_MI355X_SERIAL_WALK", raising=False)
+                back = torch.zeros_like(src)
+                eng.decompress_frame_async(dev, dev.numel(), back)
+                r = eng.result()
+                assert r.size == src.numel() and r.consumed == len(ref) and torch.equal(back, src), (name, kw, serial)
+                results.append((int(r.n_blocks), int(r.consumed)))
+            assert results[0] == results[1], (name, kw, results)
+    eng.close()
+
+
+
