@@ -163,14 +163,29 @@ LZ4F_MI355X_API void lz4f_mi355x_release_engines(void);
 /* Worst-case size of a whole frame for srcSize bytes (header + blocks + EndMark + checksum). */
 LZ4F_MI355X_API size_t lz4f_mi355x_compressFrameBound(size_t srcSize, const LZ4F_preferences_t* prefs);
 
-/* Host-pointer bulk calls: one complete frame per call, blocks batched onto the GPU
- * (pinned staging, H2D / kernels / D2H pipelined in slabs).  compressFrame == the bytes the
- * streaming API would produce for the same input fed in < blockSize slices. */
+/* Host-pointer bulk calls: one complete frame per call.  The frame's blocks go to the GPU in slabs of consecutive blocks (64 MiB),
+ * several slabs in flight - two engines per device, each on a host thread of its own - so that uploads, kernels and downloads
+ * overlap; page-locked buffers (lz4f_mi355x_host_alloc) are read and written by the DMA engines directly, pageable ones through
+ * pinned staging.  compressFrame == the bytes the streaming API would produce for the same input fed in whole blocks (up to the
+ * match finder's choice of matches, which is not deterministic). */
 LZ4F_MI355X_API size_t lz4f_mi355x_compressFrame(void* dst, size_t dstCapacity, const void* src, size_t srcSize,
                                                  const LZ4F_preferences_t* prefs);
 /* Decodes the first frame found in src. *srcConsumed (optional) = bytes of src used. */
 LZ4F_MI355X_API size_t lz4f_mi355x_decompressFrame(void* dst, size_t dstCapacity, const void* src, size_t srcSize,
                                                    size_t* srcConsumed);
+/* The same without an output buffer of the caller's: `yield` gets the decoded bytes slab by slab, in order, on the calling
+ * thread (each slab is valid during the call only).  Memory is bounded by the slabs in flight whatever the frame claims.
+ * Returns the decoded size. */
+typedef void (*lz4f_mi355x_yield_fn)(void* user, const void* data, size_t size);
+LZ4F_MI355X_API size_t lz4f_mi355x_decompressFrameTo(lz4f_mi355x_yield_fn yield, void* user, const void* src, size_t srcSize,
+                                                     size_t* srcConsumed);
+/* How many GPUs the bulk calls above deal their slabs over (round-robin, starting at the calling thread's device; default 1).
+ * Blocks of an independent-block frame need nothing from each other: no collective, the host puts the slabs' output in order.
+ * Process-wide. */
+LZ4F_MI355X_API size_t lz4f_mi355x_use_devices(int count);
+/* Page-locked host memory for the bulk calls' src / dst (what the batched conduits gather their chunks in). */
+LZ4F_MI355X_API void*  lz4f_mi355x_host_alloc(size_t size);
+LZ4F_MI355X_API void   lz4f_mi355x_host_free(void* p);
 
 /* ---- device-resident engine: everything stays in HBM, nothing synchronises with the host ---- */
 typedef struct lz4f_mi355x_engine lz4f_mi355x_engine;
@@ -264,7 +279,6 @@ LZ4F_MI355X_API size_t lz4f_mi355x_dev_xxh32(lz4f_mi355x_engine* e, const void* 
  *      C ABI; see lz4_frame_conduit_amd/csrc/conduit.hpp).  `await` returns the next input chunk
  *      (size 0 at end of stream: sets *data = NULL); `yield` receives each output ByteString. ---- */
 typedef size_t (*lz4f_mi355x_await_fn)(void* user, const void** data);
-typedef void   (*lz4f_mi355x_yield_fn)(void* user, const void* data, size_t size);
 /* compress = compressWithOutBufferSize 0 (Conduit.hsc:336-337, :457-533); prefs NULL = lz4DefaultPreferences */
 LZ4F_MI355X_API int lz4f_mi355x_conduit_compress(size_t outBufferSize, const LZ4F_preferences_t* prefs,
                                                  lz4f_mi355x_await_fn await, lz4f_mi355x_yield_fn yield, void* user,

@@ -62,6 +62,9 @@ _SIGS = {
     # PART 2
     "lz4f_mi355x_last_error": (ctypes.c_char_p, []), "lz4f_mi355x_device_count": (ctypes.c_int, []), "lz4f_mi355x_set_device": (c_size_t, [ctypes.c_int]),
     "lz4f_mi355x_release_engines": (None, []),
+    "lz4f_mi355x_decompressFrameTo": (c_size_t, [YIELD_FN, c_void_p, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]),
+    "lz4f_mi355x_use_devices": (c_size_t, [ctypes.c_int]),
+    "lz4f_mi355x_host_alloc": (c_void_p, [c_size_t]), "lz4f_mi355x_host_free": (None, [c_void_p]),
     "lz4f_mi355x_compressFrameBound": (c_size_t, [c_size_t, PP]),
     "lz4f_mi355x_compressFrame": (c_size_t, [c_void_p, c_size_t, c_void_p, c_size_t, PP]),
     "lz4f_mi355x_decompressFrame": (c_size_t, [c_void_p, c_size_t, c_void_p, c_size_t, ctypes.POINTER(c_size_t)]),

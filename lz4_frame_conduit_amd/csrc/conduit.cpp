@@ -197,36 +197,74 @@ void decompress(const Await& await, const Yield& yield)
 }
 
 // ---- batched variants (new) ---------------------------------------------
-// compressBatched: same frame bytes as compressWithPreferences, but input is gathered until
-// `batchBytes` are available so that one LZ4F_compressUpdate call hands many blocks to the GPU.
+// compressBatched: a frame like compressWithPreferences makes, but the input is gathered - in page-locked memory, which the
+// GPU's DMA engines read directly - until `batchBytes` are there, and every batch's whole blocks go through the bulk path
+// (pipeline.hip: slabs of blocks in flight, over lz4f_mi355x_use_devices() GPUs).  A linked frame's batches keep the
+// 64 KiB in front of them.
+namespace {
+struct Pinned {
+    uint8_t* p = nullptr; size_t cap = 0;
+    void ensure(size_t n) { if (n <= cap) return; uint8_t* q = (uint8_t*)lz4f_mi355x_host_alloc(n); if (!q) throw std::runtime_error(std::string("lz4frame error: ") + lz4f_mi355x_last_error()); if (p) { /* caller copies what it needs first */ lz4f_mi355x_host_free(p); } p = q; cap = n; }
+    ~Pinned() { lz4f_mi355x_host_free(p); }
+};
+}
 void compressBatched(size_t batchBytes, const LZ4F_preferences_t* prefsIn, const Await& await, const Yield& yield)
 {
-    ScopedCctx s(prefsIn);
-    std::vector<uint8_t> out(LZ4F_HEADER_SIZE_MAX), in;
-    const size_t headerSize = handleLz4Error(LZ4F_compressBegin(s.ctx, out.data(), out.size(), &s.prefs));
-    yield(Slice{out.data(), headerSize});
-    auto flushBatch = [&]() {
-        if (in.empty()) return;
-        const size_t bound = handleLz4Error(LZ4F_compressBound(in.size(), &s.prefs));
-        if (out.size() < bound) out.resize(bound);
-        const size_t w = handleLz4Error(LZ4F_compressUpdate(s.ctx, out.data(), out.size(), in.data(), in.size(), NULL));
-        if (w) yield(Slice{out.data(), w});
-        in.clear();
+    LZ4F_preferences_t prefs; memset(&prefs, 0, sizeof(prefs));
+    if (prefsIn) prefs = *prefsIn;
+    if (prefs.compressionLevel > 2) handleLz4Error(make_err(LZ4F_ERROR_compressionLevel_invalid));
+    if (prefs.frameInfo.blockSizeID == 0) prefs.frameInfo.blockSizeID = LZ4F_max64KB;
+    const size_t bs = block_size_of(prefs.frameInfo.blockSizeID);
+    if (!bs) handleLz4Error(make_err(LZ4F_ERROR_maxBlockSize_invalid));
+    const bool linked = prefs.frameInfo.blockMode == LZ4F_blockLinked, bck = prefs.frameInfo.blockChecksumFlag != 0;
+    const bool cck = prefs.frameInfo.contentChecksumFlag == LZ4F_contentChecksumEnabled;
+    uint8_t hdr[LZ4F_HEADER_SIZE_MAX];
+    const size_t headerSize = write_frame_header(hdr, prefs);
+    yield(Slice{hdr, headerSize});
+    if (lz4f_mi355x_device_count() <= 0) { set_last_error("no usable HIP device: liblz4f_mi355x has no CPU fallback"); handleLz4Error(make_err(LZ4F_ERROR_GENERIC)); }
+    if (batchBytes < bs) batchBytes = bs;
+    const size_t HIST = 65536;
+    Pinned in, out;
+    in.ensure(HIST + batchBytes + bs + (1u << 20));              // [64 KiB of the batch before][this batch ...]
+    size_t fill = 0, hist = 0;                                  // bytes gathered behind in.p + HIST; valid history in front of them
+    uint64_t total = 0;
+    Xxh32State xxh; xxh.reset(0);
+    auto flushBatch = [&](bool last) {
+        const size_t n = last ? fill : (fill / bs) * bs;         // whole blocks; at the end also the short one
+        if (!n) return;
+        const size_t cap = n + (n / bs + 2) * 8 + 64;
+        out.ensure(cap);
+        size_t w = 0;
+        handleLz4Error(pipe_compress_blocks(in.p + HIST, n, (uint32_t)bs, linked, bck, out.p, out.cap, &w, hist));
+        if (w) yield(Slice{out.p, w});
+        if (linked) { const size_t keep = std::min(HIST, hist + n); memmove(in.p + HIST - keep, in.p + HIST + n - keep, keep); hist = keep; }
+        memmove(in.p + HIST, in.p + HIST + n, fill - n);
+        fill -= n;
     };
-    Slice bs;
-    while (await(bs)) {
-        in.insert(in.end(), bs.data, bs.data + bs.size);
-        if (in.size() >= batchBytes) flushBatch();
+    Slice bsl;
+    while (await(bsl)) {
+        const uint8_t* q = bsl.data; size_t left = bsl.size;
+        if (cck) xxh.update(q, left);
+        total += left;
+        while (left) {
+            const size_t room = in.cap - HIST - fill;
+            const size_t take = std::min(room, left);
+            memcpy(in.p + HIST + fill, q, take);
+            fill += take; q += take; left -= take;
+            if (fill >= batchBytes) flushBatch(false);
+        }
     }
-    flushBatch();
-    const size_t footerSize = handleLz4Error(LZ4F_compressBound(0, &s.prefs));
-    if (out.size() < footerSize) out.resize(footerSize);
-    const size_t fw = handleLz4Error(LZ4F_compressEnd(s.ctx, out.data(), out.size(), NULL));
-    yield(Slice{out.data(), fw});
+    flushBatch(true);
+    uint8_t tail[8]; size_t tn = 4;
+    tail[0] = tail[1] = tail[2] = tail[3] = 0;
+    if (cck) { const uint32_t d = xxh.digest(); tail[4] = (uint8_t)d; tail[5] = (uint8_t)(d >> 8); tail[6] = (uint8_t)(d >> 16); tail[7] = (uint8_t)(d >> 24); tn = 8; }
+    yield(Slice{tail, tn});
+    if (prefs.frameInfo.contentSize && prefs.frameInfo.contentSize != total) handleLz4Error(make_err(LZ4F_ERROR_frameSize_wrong));
 }
 
-// decompressBatched: gathers the frame and decodes all of its blocks in one bulk call
-// (lz4f_mi355x_decompressFrame: host walk of the size words, slabs of blocks per launch).
+// decompressBatched: gathers the stream and decodes each frame's blocks through the bulk path
+// (lz4f_mi355x_decompressFrameTo: host walk of the size words, slabs of blocks in flight), yielding slab by slab - what is held
+// in memory is bounded by the slabs in flight, whatever block size the header names and however short the blocks are.
 void decompressBatched(const Await& await, const Yield& yield)
 {
     std::vector<uint8_t> frame;
@@ -239,7 +277,8 @@ void decompressBatched(const Await& await, const Yield& yield)
     // frames are skipped, concatenated frames are all decoded, any header the format allows is accepted.
     auto le32 = [&](size_t at) { return (uint32_t)frame[at] | ((uint32_t)frame[at + 1] << 8) | ((uint32_t)frame[at + 2] << 16) | ((uint32_t)frame[at + 3] << 24); };
     size_t at = 0;
-    std::vector<uint8_t> out;
+    struct Ctx { const Yield* y; } ctx{&yield};
+    auto to_yield = [](void* user, const void* data, size_t size) { (*((Ctx*)user)->y)(Slice{(const uint8_t*)data, size}); };
     while (at < frame.size()) {
         const uint8_t* f = frame.data() + at;
         const size_t left = frame.size() - at;
@@ -254,8 +293,8 @@ void decompressBatched(const Await& await, const Yield& yield)
         }
         ParsedHeader ph;
         handleLz4Error(parse_frame_header(f, left, &ph));                  // frameType_unknown for anything else
-        // capacity: blocks * maxBlockSize from a walk of the size words
-        size_t cap = 0, pos = ph.header_size;
+        // the frame must be complete (the reference's protocol error for a stream that ends early)
+        size_t pos = ph.header_size;
         for (;;) {
             if (left - pos < 4) throw std::runtime_error("lz4 decompress error: stream ended before EndMark");
             const uint32_t w = le32(at + pos);
@@ -263,12 +302,9 @@ void decompressBatched(const Await& await, const Yield& yield)
             const size_t step = 4 + (size_t)(w & 0x7FFFFFFFu) + (ph.info.blockChecksumFlag ? 4 : 0);
             if (left - pos < step) throw std::runtime_error("lz4 decompress error: stream ended before EndMark");
             pos += step;
-            cap += ph.max_block;
         }
-        out.resize(cap ? cap : 1);
         size_t used = 0;
-        const size_t n = handleLz4Error(lz4f_mi355x_decompressFrame(out.data(), cap, f, left, &used));
-        yield(Slice{out.data(), n});
+        handleLz4Error(lz4f_mi355x_decompressFrameTo(to_yield, &ctx, f, left, &used));
         at += used;
     }
 }

@@ -576,6 +576,22 @@ static void big_memcpy(void* dst, const void* src, size_t n)
 
 // Host buffer <-> device through the pinned staging buffer, in pieces: the copy between the caller's pageable memory and the
 // staging buffer (CPU threads) of one piece runs while the DMA of the piece before is in flight, instead of one after the other.
+// Is `p` page-locked memory the DMA engines can reach directly (hipHostMalloc / hipHostRegister: lz4f_mi355x_host_alloc,
+// the conduits' batch buffers)?  Then no staging copy is needed.
+// One upload and one download at a time per device.  Engines that share a device share its host link: two uploads side by
+// side each take twice as long, and - symmetric as they are - the engines then also download side by side, so the link is never
+// busy in both directions (measured: 32 GiB/s).  With a token per direction they fall out of step by themselves: one engine's
+// upload runs beside the other's kernels and download.
+namespace { std::mutex g_up_mu[16], g_down_mu[16]; }
+static std::mutex& up_token(int device) { return g_up_mu[(unsigned)device % 16]; }
+static std::mutex& down_token(int device) { return g_down_mu[(unsigned)device % 16]; }
+
+bool lz4f::is_pinned_host(const void* p)
+{
+    hipPointerAttribute_t a; memset(&a, 0, sizeof(a));
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
 static const size_t XFER_PIECE = (size_t)32 << 20;
 static hipError_t staged_h2d(void* d_dst, void* pinned, const void* src, size_t n, hipStream_t st)
 {
@@ -610,10 +626,10 @@ static hipError_t staged_d2h(void* dst, void* pinned, const void* d_src, size_t 
     return e;
 }
 
-size_t lz4f_mi355x_engine::compress_blocks_host(const uint8_t* src, size_t n, const uint8_t* hist, size_t hist_len,
-                                                uint32_t block_size, bool linked, bool block_checksum, uint8_t* dst, size_t dst_cap, size_t* written)
+size_t lz4f_mi355x_engine::slab_compress(const uint8_t* src, size_t n, const uint8_t* hist, size_t hist_len, uint32_t block_size, bool linked,
+                                         bool block_checksum, bool src_pinned, size_t* size)
 {
-    *written = 0;
+    *size = 0;
     if (n == 0) return 0;
     HIP_TRY(hipSetDevice(device));
     hipStream_t st = (hipStream_t)stream;
@@ -622,23 +638,54 @@ size_t lz4f_mi355x_engine::compress_blocks_host(const uint8_t* src, size_t n, co
     const size_t total = hist_len + n;
     const size_t nblocks = (n + block_size - 1) / block_size;
     const size_t out_cap = n + nblocks * 8 + 64;
-    if (h_in.ensure(total) || d_in.ensure(total + 64) || d_out.ensure(out_cap) || h_out.ensure(out_cap + sizeof(ResultRec)) || res.ensure(sizeof(ResultRec)))
+    if ((!src_pinned && h_in.ensure(total)) || h_small.ensure(65536 + 256) || d_in.ensure(total + 64) || d_out.ensure(out_cap) || res.ensure(sizeof(ResultRec)))
         return make_err(LZ4F_ERROR_allocation_failed);
-    if (hist_len) memcpy(h_in.p, hist, hist_len);
-    if (hist_len) HIP_TRY(hipMemcpyAsync(d_in.p, h_in.p, hist_len, hipMemcpyHostToDevice, st));
-    HIP_TRY(staged_h2d((uint8_t*)d_in.p + hist_len, (uint8_t*)h_in.p + hist_len, src, n, st));
+    {
+        std::lock_guard<std::mutex> up(up_token(device));
+        if (hist_len) {
+            if (src_pinned && hist + hist_len == src) HIP_TRY(hipMemcpyAsync(d_in.p, hist, hist_len, hipMemcpyHostToDevice, st));      // (the history sits in front of the input, in the same pinned buffer)
+            else { memcpy(h_small.p, hist, hist_len); HIP_TRY(hipMemcpyAsync(d_in.p, h_small.p, hist_len, hipMemcpyHostToDevice, st)); }
+        }
+        if (src_pinned) HIP_TRY(hipMemcpyAsync((uint8_t*)d_in.p + hist_len, src, n, hipMemcpyHostToDevice, st));
+        else HIP_TRY(staged_h2d((uint8_t*)d_in.p + hist_len, (uint8_t*)h_in.p + hist_len, src, n, st));
+        if (n >= ((size_t)8 << 20)) HIP_TRY(hipStreamSynchronize(st));      // (bulk slabs: hold the token until the bytes are over)
+    }
     CompressJob j; memset(&j, 0, sizeof(j));
     j.d_src = (const uint8_t*)d_in.p; j.src_size = total; j.first_off = hist_len; j.block_size = block_size;
     j.linked = linked; j.block_checksum = block_checksum; j.endmark = false; j.header_size = 0;
     size_t r = launch_compress(j, (uint8_t*)d_out.p, out_cap, (lz4f_mi355x_result*)res.p, nullptr);
     if (is_err(r)) return r;
-    ResultRec* hr = (ResultRec*)((uint8_t*)h_out.p + out_cap);
+    ResultRec* hr = (ResultRec*)((uint8_t*)h_small.p + 65536 + 64);
     HIP_TRY(hipMemcpyAsync(hr, res.p, sizeof(ResultRec), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (hr->status != ST_OK) { set_last_error("device compress status %u", hr->status); return make_err((int)hr->status); }
-    if (hr->size > dst_cap) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
-    HIP_TRY(staged_d2h(dst, h_out.p, d_out.p, hr->size, st));
-    *written = hr->size;
+    *size = hr->size;
+    return 0;
+}
+
+size_t lz4f_mi355x_engine::slab_fetch(uint8_t* dst, size_t size, size_t d_off, bool dst_pinned)
+{
+    if (size == 0) return 0;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    if (!dst_pinned && h_out.ensure(size + 64)) return make_err(LZ4F_ERROR_allocation_failed);
+    std::lock_guard<std::mutex> down(down_token(device));
+    if (dst_pinned) { HIP_TRY(hipMemcpyAsync(dst, (const uint8_t*)d_out.p + d_off, size, hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); return 0; }
+    HIP_TRY(staged_d2h(dst, h_out.p, (const uint8_t*)d_out.p + d_off, size, st));
+    return 0;
+}
+
+size_t lz4f_mi355x_engine::compress_blocks_host(const uint8_t* src, size_t n, const uint8_t* hist, size_t hist_len,
+                                                uint32_t block_size, bool linked, bool block_checksum, uint8_t* dst, size_t dst_cap, size_t* written)
+{
+    *written = 0;
+    size_t size = 0;
+    size_t r = slab_compress(src, n, hist, hist_len, block_size, linked, block_checksum, false, &size);
+    if (is_err(r)) return r;
+    if (size > dst_cap) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
+    r = slab_fetch(dst, size, 0, false);
+    if (is_err(r)) return r;
+    *written = size;
     return 0;
 }
 
@@ -647,8 +694,8 @@ static size_t status_to_err(uint32_t st)
     return st == ST_OK ? 0 : make_err((int)st);
 }
 
-size_t lz4f_mi355x_engine::run_decode_slab(const uint8_t* frame_part, size_t part_len, const std::vector<lz4f_mi355x_block>& entries,
-                                           const ParsedHeader& ph, const uint8_t* hist, size_t hist_len, uint8_t* dst, size_t dst_room, size_t* got)
+size_t lz4f_mi355x_engine::slab_decode(const uint8_t* frame_part, size_t part_len, const std::vector<lz4f_mi355x_block>& entries,
+                                       const ParsedHeader& ph, const uint8_t* hist, size_t hist_len, bool src_pinned, size_t* got)
 {
     HIP_TRY(hipSetDevice(device));
     hipStream_t st = (hipStream_t)stream;
@@ -656,31 +703,50 @@ size_t lz4f_mi355x_engine::run_decode_slab(const uint8_t* frame_part, size_t par
     if (!linked) hist_len = 0;
     const size_t nb = entries.size();
     // the device buffer always has room for every block at full size: blocks are decoded at provisional positions and
-    // compacted when some are short (frames written with LZ4F_flush); only what is actually produced must fit `dst`
+    // compacted when some are short (frames written with LZ4F_flush); only what is actually produced must fit the caller's buffer
     const size_t out_room = nb * ph.max_block;
     const size_t tbytes = nb * sizeof(BlockOut);
-    if (h_in.ensure(part_len + tbytes + hist_len + 64) || d_in.ensure(part_len + 64) || d_out.ensure(hist_len + out_room + 64) ||
-        h_out.ensure(out_room + sizeof(ResultRec) + 64) || res.ensure(sizeof(ResultRec)) || table.ensure((nb + 1) * sizeof(BlockOut)))
+    if (h_in.ensure((src_pinned ? 0 : part_len) + tbytes + hist_len + 128) || d_in.ensure(part_len + 64) || d_out.ensure(hist_len + out_room + 64) ||
+        res.ensure(sizeof(ResultRec)) || table.ensure((nb + 1) * sizeof(BlockOut)))
         return make_err(LZ4F_ERROR_allocation_failed);
     uint8_t* hp = (uint8_t*)h_in.p;
-    memcpy(hp + part_len, entries.data(), tbytes);
-    if (hist_len) memcpy(hp + part_len + tbytes, hist, hist_len);
-    HIP_TRY(staged_h2d(d_in.p, hp, frame_part, part_len, st));
-    HIP_TRY(hipMemcpyAsync(table.p, hp + part_len, tbytes, hipMemcpyHostToDevice, st));
-    if (hist_len) HIP_TRY(hipMemcpyAsync(d_out.p, hp + part_len + tbytes, hist_len, hipMemcpyHostToDevice, st));
+    const size_t at_tab = src_pinned ? 0 : part_len;
+    memcpy(hp + at_tab, entries.data(), tbytes);
+    if (hist_len) memcpy(hp + at_tab + tbytes, hist, hist_len);
+    {
+        std::lock_guard<std::mutex> up(up_token(device));
+        if (src_pinned) HIP_TRY(hipMemcpyAsync(d_in.p, frame_part, part_len, hipMemcpyHostToDevice, st));
+        else HIP_TRY(staged_h2d(d_in.p, hp, frame_part, part_len, st));
+        HIP_TRY(hipMemcpyAsync(table.p, hp + at_tab, tbytes, hipMemcpyHostToDevice, st));
+        if (hist_len) HIP_TRY(hipMemcpyAsync(d_out.p, hp + at_tab + tbytes, hist_len, hipMemcpyHostToDevice, st));
+        if (part_len >= ((size_t)8 << 20)) HIP_TRY(hipStreamSynchronize(st));
+    }
     DecompressJob j; memset(&j, 0, sizeof(j));
     j.d_frame = (const uint8_t*)d_in.p; j.frame_cap = part_len; j.d_dst = (uint8_t*)d_out.p + hist_len; j.dst_cap = out_room; j.hist0 = hist_len;
     j.block_size = (uint32_t)ph.max_block; j.linked = linked; j.block_checksum = ph.info.blockChecksumFlag != 0;
     j.table_in_place = true; j.n_blocks = (uint32_t)nb; j.max_blocks = (uint32_t)nb;
     size_t r = launch_decompress(j, (lz4f_mi355x_result*)res.p);
     if (is_err(r)) return r;
-    ResultRec* hr = (ResultRec*)((uint8_t*)h_out.p + out_room + 32 - ((out_room + 32) & 7) + 8);
+    ResultRec* hr = (ResultRec*)(hp + at_tab + tbytes + hist_len + 8 - ((at_tab + tbytes + hist_len) & 7) + 8);
     HIP_TRY(hipMemcpyAsync(hr, res.p, sizeof(ResultRec), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (hr->status != ST_OK) { set_last_error("device decode status %u at block %u", hr->status, hr->first_bad_block); return status_to_err(hr->status); }
-    if (hr->size > dst_room) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
-    HIP_TRY(staged_d2h(dst, h_out.p, (uint8_t*)d_out.p + hist_len, hr->size, st));
     *got = hr->size;
+    return 0;
+}
+
+size_t lz4f_mi355x_engine::run_decode_slab(const uint8_t* frame_part, size_t part_len, const std::vector<lz4f_mi355x_block>& entries,
+                                           const ParsedHeader& ph, const uint8_t* hist, size_t hist_len, uint8_t* dst, size_t dst_room, size_t* got)
+{
+    const bool linked = ph.info.blockMode == LZ4F_blockLinked;
+    if (!linked) hist_len = 0;
+    size_t n = 0;
+    size_t r = slab_decode(frame_part, part_len, entries, ph, hist, hist_len, false, &n);
+    if (is_err(r)) return r;
+    if (n > dst_room) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
+    r = slab_fetch(dst, n, hist_len, false);
+    if (is_err(r)) return r;
+    *got = n;
     return 0;
 }
 
@@ -774,6 +840,13 @@ size_t lz4f_mi355x_engine_create(lz4f_mi355x_engine** out, int device, void* hip
 }
 size_t lz4f_mi355x_engine_free(lz4f_mi355x_engine* e) { delete e; return 0; }
 void lz4f_mi355x_release_engines(void) { lz4f::release_idle_engines(); }
+void* lz4f_mi355x_host_alloc(size_t size)
+{
+    void* p = nullptr;
+    if (hipSetDevice(lz4f::selected_device()) != hipSuccess || hipHostMalloc(&p, size ? size : 1, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); set_last_error("hipHostMalloc(%zu) failed", size); return nullptr; }
+    return p;
+}
+void lz4f_mi355x_host_free(void* p) { if (p) (void)hipHostFree(p); }
 void* lz4f_mi355x_engine_stream(lz4f_mi355x_engine* e) { return e ? e->stream : nullptr; }
 
 size_t lz4f_mi355x_engine_set_timing(lz4f_mi355x_engine* e, int enable)

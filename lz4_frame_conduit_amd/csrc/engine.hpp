@@ -3,6 +3,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -95,6 +96,13 @@ struct lz4f_mi355x_engine {
     // history (host) precede them when linked.  Appends [size word][payload][checksum] per block to out.
     size_t compress_blocks_host(const uint8_t* src, size_t n, const uint8_t* hist, size_t hist_len,
                                 uint32_t block_size, bool linked, bool block_checksum, uint8_t* dst, size_t dst_cap, size_t* written);
+    // The same in two halves, for the pipelined bulk calls (pipeline.hip): upload + kernels + result (the blocks stay in d_out),
+    // then the download.  `*_pinned`: the host buffer is page-locked, no staging copy.
+    size_t slab_compress(const uint8_t* src, size_t n, const uint8_t* hist, size_t hist_len, uint32_t block_size, bool linked, bool block_checksum,
+                         bool src_pinned, size_t* size);
+    size_t slab_fetch(uint8_t* dst, size_t size, size_t d_off, bool dst_pinned);
+    size_t slab_decode(const uint8_t* frame_part, size_t part_len, const std::vector<lz4f_mi355x_block>& entries, const lz4f::ParsedHeader& ph,
+                       const uint8_t* hist, size_t hist_len, bool src_pinned, size_t* got);
     // Decode one compressed block payload (host; followed by its 4-byte checksum when bck) with `hist_len`
     // bytes of history (host, linked frames).  The checksum is verified and the block decoded on the GPU;
     // the decoded bytes land in dst (host).
@@ -125,5 +133,14 @@ struct EngineLease {
 };
 size_t new_engine(lz4f_mi355x_engine** out, int device, void* stream, bool borrow);
 int    selected_device();
+bool   is_pinned_host(const void* p);
+// pipelined bulk paths (pipeline.hip)
+int    bulk_devices();
+void   set_bulk_devices(int n);
+// hist_before: valid input bytes in front of src (a linked frame's blocks reach 64 KiB back)
+size_t pipe_compress_blocks(const uint8_t* src, size_t n, uint32_t block_size, bool linked, bool bck, uint8_t* dst, size_t cap, size_t* written,
+                            size_t hist_before = 0);
+size_t pipe_decompress_frame(const uint8_t* frame, size_t n, const ParsedHeader& ph, uint8_t* flat, size_t flat_cap,
+                             const std::function<void(const uint8_t*, size_t)>* sink, size_t* decoded, size_t* consumed);
 uint32_t pick_chunk_size(uint32_t block_size);
 }

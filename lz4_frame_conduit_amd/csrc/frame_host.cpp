@@ -14,6 +14,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
+#include <thread>
 #include <new>
 #include <vector>
 
@@ -669,36 +671,40 @@ size_t lz4f_mi355x_compressFrameBound(size_t srcSize, const LZ4F_preferences_t* 
 
 size_t lz4f_mi355x_compressFrame(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const LZ4F_preferences_t* prefs)
 {
-    // begin / one big update (slabs of whole blocks go to the GPU in one launch each) / end
-    LZ4F_cctx* c = nullptr;
-    size_t r = LZ4F_createCompressionContext(&c, LZ4F_VERSION);
+    // header / all blocks through the slab pipeline (pipeline.hip: several slabs in flight, over lz4f_mi355x_use_devices() GPUs) /
+    // EndMark / content checksum.  Same bytes as the streaming API gives for the same input fed in whole blocks.
+    LZ4F_preferences_t p; memset(&p, 0, sizeof(p));
+    if (prefs) p = *prefs;
+    if (p.compressionLevel > 2) { set_last_error("compressionLevel %d: only the fast encoder exists in liblz4f_mi355x", p.compressionLevel); return make_err(LZ4F_ERROR_compressionLevel_invalid); }
+    if (p.frameInfo.blockSizeID == 0) p.frameInfo.blockSizeID = LZ4F_max64KB;
+    const size_t bs = block_size_of(p.frameInfo.blockSizeID);
+    if (!bs) return make_err(LZ4F_ERROR_maxBlockSize_invalid);
+    if (dstCapacity < LZ4F_HEADER_SIZE_MAX) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
+    if (p.frameInfo.contentSize && p.frameInfo.contentSize != srcSize) return make_err(LZ4F_ERROR_frameSize_wrong);
+    uint8_t* d = (uint8_t*)dst;
+    size_t used = write_frame_header(d, p);
+    // the content checksum is one serial chain over the input (~6 GB/s on a core): on a thread of its own, beside the transfers
+    uint32_t cck = 0;
+    std::thread hasher;
+    const bool want_cck = p.frameInfo.contentChecksumFlag == LZ4F_contentChecksumEnabled;
+    if (want_cck) hasher = std::thread([&] { cck = xxh32_host(src, srcSize); });
+    size_t written = 0;
+    size_t r = pipe_compress_blocks((const uint8_t*)src, srcSize, (uint32_t)bs, p.frameInfo.blockMode == LZ4F_blockLinked, p.frameInfo.blockChecksumFlag != 0,
+                                    d + used, dstCapacity - used, &written);
+    if (want_cck) hasher.join();
     if (is_err(r)) return r;
-    uint8_t* d = (uint8_t*)dst; size_t used = 0;
-    const uint8_t* s = (const uint8_t*)src;
-    r = LZ4F_compressBegin(c, d, dstCapacity, prefs);
-    if (is_err(r)) goto done;
-    used = r;
-    {
-        const size_t slab = (size_t)256 << 20;                  // multiple of every block size
-        for (size_t off = 0; off < srcSize; off += slab) {
-            const size_t n = std::min(slab, srcSize - off);
-            r = LZ4F_compressUpdate(c, d + used, dstCapacity - used, s + off, n, NULL);
-            if (is_err(r)) goto done;
-            used += r;
-        }
-    }
-    r = LZ4F_compressEnd(c, d + used, dstCapacity - used, NULL);
-    if (is_err(r)) goto done;
-    used += r; r = used;
-done:
-    LZ4F_freeCompressionContext(c);
-    return r;
+    used += written;
+    if (dstCapacity - used < (size_t)(want_cck ? 8 : 4)) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
+    st32(d + used, 0); used += 4;
+    if (want_cck) { st32(d + used, cck); used += 4; }
+    return used;
 }
 
-size_t lz4f_mi355x_decompressFrame(void* dst, size_t dstCapacity, const void* src, size_t srcSize, size_t* srcConsumed)
+static size_t decompress_frame_common(void* dst, size_t dstCapacity, const void* src, size_t srcSize, size_t* srcConsumed,
+                                      const std::function<void(const uint8_t*, size_t)>* sink)
 {
-    // Host walk of the size words (one 4-byte read per block), then ONE device call for all blocks
-    // of a slab: payloads up, table up, decode, output down.
+    // Host walk of the size words (one 4-byte read per block), then slabs of blocks through the pipeline:
+    // payloads up, table up, decode, output down - several slabs in flight.
     const uint8_t* s = (const uint8_t*)src;
     if (srcConsumed) *srcConsumed = 0;
     if (srcSize < 7) return make_err(LZ4F_ERROR_frameHeader_incomplete);
@@ -710,14 +716,31 @@ size_t lz4f_mi355x_decompressFrame(void* dst, size_t dstCapacity, const void* sr
     ParsedHeader ph;
     size_t hs = parse_frame_header(s, srcSize, &ph);
     if (is_err(hs)) return hs;
-    EngineLease eng;
-    size_t r = eng.get();
-    if (is_err(r)) return r;
     size_t decoded = 0, consumed = 0;
-    r = eng->decompress_frame_host(s, srcSize, ph, (uint8_t*)dst, dstCapacity, &decoded, &consumed);
+    size_t r = pipe_decompress_frame(s, srcSize, ph, sink ? nullptr : (uint8_t*)dst, dstCapacity, sink, &decoded, &consumed);
     if (is_err(r)) return r;
     if (srcConsumed) *srcConsumed = consumed;
     return decoded;
+}
+
+size_t lz4f_mi355x_decompressFrame(void* dst, size_t dstCapacity, const void* src, size_t srcSize, size_t* srcConsumed)
+{
+    return decompress_frame_common(dst, dstCapacity, src, srcSize, srcConsumed, nullptr);
+}
+
+size_t lz4f_mi355x_decompressFrameTo(lz4f_mi355x_yield_fn yield, void* user, const void* src, size_t srcSize, size_t* srcConsumed)
+{
+    if (!yield) return make_err(LZ4F_ERROR_GENERIC);
+    const std::function<void(const uint8_t*, size_t)> sink = [&](const uint8_t* p, size_t n) { yield(user, p, n); };
+    return decompress_frame_common(nullptr, 0, src, srcSize, srcConsumed, &sink);
+}
+
+size_t lz4f_mi355x_use_devices(int count)
+{
+    const int have = lz4f_mi355x_device_count();
+    if (count < 1 || count > have) { set_last_error("use_devices(%d): %d devices are visible", count, have); return make_err(LZ4F_ERROR_GENERIC); }
+    set_bulk_devices(count);
+    return 0;
 }
 
 }  // extern "C"

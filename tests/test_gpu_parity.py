@@ -350,6 +350,30 @@ def test_batched_decoder_walks_whole_streams(L, golden, named_inputs):
         want = b"".join(b"" if p == "SKIP" else frames[p][1] for p in parts)
         for chunks in ([stream], [stream[:1], stream[1:5], stream[5:9], stream[9:70000], stream[70000:]]):
             assert b"".join(conduit.decompressBatched(chunks)) == want, label
+    # many short blocks under a big blockSizeID (a flushing writer: 16 KiB blocks in a 4 MiB-block frame): the batched decoder
+    # hands the output over slab by slab and must not size anything as blocks x maxBlockSize (24 MiB here would ask for 6 GiB)
+    big = datagen.synth_text(24 << 20, 5).tobytes()
+    flushed = oracle.conduit_compress(big, oracle.mkprefs(7, 1, 1, 0, 0, 0, 1), 16384)       # autoFlush: a block per 16 KiB slice
+    pieces = list(conduit.decompressBatched([flushed]))
+    assert len(pieces) >= 2 and sha(b"".join(pieces)) == sha(big)
+    # the bulk calls over page-locked buffers, and over pageable ones, give the same frames' content
+    import ctypes
+    n = len(big)
+    p = prefs_of(dict(bsid=6, indep=1, cck=1))
+    cap = L.lz4f_mi355x_compressFrameBound(n, ctypes.byref(p))
+    hp = [L.lz4f_mi355x_host_alloc(x) for x in (n, cap, n + 8)]
+    assert all(hp)
+    try:
+        ctypes.memmove(hp[0], big, n)
+        r = L.lz4f_mi355x_compressFrame(hp[1], cap, hp[0], n, ctypes.byref(p))
+        assert not L.LZ4F_isError(r), L.LZ4F_getErrorName(r)
+        fr = ctypes.string_at(hp[1], r)
+        assert oracle.decompress_frame(fr, n + 8) == (big, len(fr))
+        used = ctypes.c_size_t(0)
+        r2 = L.lz4f_mi355x_decompressFrame(hp[2], n + 8, hp[1], r, ctypes.byref(used))
+        assert r2 == n and used.value == r and ctypes.string_at(hp[2], n) == big
+    finally:
+        for x in hp: L.lz4f_mi355x_host_free(x)
     # what must still fail, with liblz4's names
     with pytest.raises(conduit.Lz4FrameError, match="ERROR_frameType_unknown"):
         conduit.decompressBatched([frames["plain"][0] + b"\x01\x02\x03\x04\x05\x06\x07\x08"])
