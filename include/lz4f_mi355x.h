@@ -263,6 +263,14 @@ LZ4F_MI355X_API size_t lz4f_mi355x_dev_decompressBlocks(lz4f_mi355x_engine* e, v
  * the bytes that come out.  Independent blocks only.  A stream with more sequences than the index has room for (about one
  * per 64 input bytes at the recommended size) gets an index marked unusable. */
 LZ4F_MI355X_API size_t lz4f_mi355x_dev_index_size(size_t srcSize, const LZ4F_preferences_t* prefs);       /* recommended bytes for d_index */
+/* IN-BAND: with d_index == NULL and indexCapacity == LZ4F_MI355X_INBAND (d_table and d_result may then be NULL too) the index
+ * and the list of the blocks' positions travel in the byte stream itself, as a skippable frame (magic 0x184D2A5E) right behind
+ * the LZ4 frame: result.size includes it, d_dst must be 16-byte aligned and hold compressFrameBound + trailer_bound bytes.
+ * liblz4, the `lz4` tool and the reference's `decompress` (Conduit.hsc:598: it stops at the EndMark) decode such a stream to the
+ * same bytes; lz4f_mi355x_dev_decompressFrame finds the trailer from the stream's last 16 bytes and, after checking it against
+ * the frame itself, skips the walk over the size words and parses with the index. */
+#define LZ4F_MI355X_INBAND ((size_t)-1)
+LZ4F_MI355X_API size_t lz4f_mi355x_trailer_bound(size_t srcSize, const LZ4F_preferences_t* prefs);
 LZ4F_MI355X_API size_t lz4f_mi355x_dev_compressFrameIndexed(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize,
                                                             const LZ4F_preferences_t* prefs, lz4f_mi355x_result* d_result,
                                                             lz4f_mi355x_block* d_table, void* d_index, size_t indexCapacity);

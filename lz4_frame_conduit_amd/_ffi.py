@@ -74,6 +74,7 @@ _SIGS = {
     "lz4f_mi355x_dev_compressFrame": (c_size_t, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, PP, c_void_p, c_void_p]),
     "lz4f_mi355x_dev_decompressFrame": (c_size_t, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "lz4f_mi355x_dev_index_size": (c_size_t, [c_size_t, PP]),
+    "lz4f_mi355x_trailer_bound": (c_size_t, [c_size_t, PP]),
     "lz4f_mi355x_dev_compressFrameIndexed": (c_size_t, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, PP, c_void_p, c_void_p, c_void_p, c_size_t]),
     "lz4f_mi355x_dev_decompressBlocksIndexed": (c_size_t, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, ctypes.c_uint32, ctypes.POINTER(FrameInfo), c_void_p, c_size_t, c_void_p]),
     "lz4f_mi355x_dev_decompressBlocks": (c_size_t, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p, ctypes.c_uint32, ctypes.POINTER(FrameInfo), c_void_p]),

@@ -57,11 +57,11 @@ __device__ __forceinline__ void pt_load16(const uint8_t* __restrict__ in, uint32
 // tables inside the buffer the caller named, its sequences inside the descriptor workspace the engine has.  flags[0] != 0
 // sends the call to the generic decoder; flags[8] / flags[9] carry the entry and sequence counts to the kernels behind.
 __global__ void k_check_index(const void* __restrict__ ix, uint64_t ix_size, uint32_t n_blocks, uint32_t chunks_per_block, uint32_t chunk_size,
-                              uint64_t seq_cap, uint32_t* __restrict__ flags)
+                              uint64_t seq_cap, uint32_t* __restrict__ flags, const ResultRec* __restrict__ res = nullptr)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const IxHeader hd = *(const IxHeader*)ix;
-    const bool ok = hd.magic == IX_MAGIC && hd.n_blocks == n_blocks && hd.chunks_per_block == chunks_per_block && hd.stride == IX_STRIDE &&
+    const bool ok = (!res || (res->status == ST_OK && res->n_blocks == n_blocks)) && hd.magic == IX_MAGIC && hd.n_blocks == n_blocks && hd.chunks_per_block == chunks_per_block && hd.stride == IX_STRIDE &&
                     hd.total_entries <= (uint64_t)n_blocks * chunks_per_block * ix_max_entries_per_chunk(chunk_size) &&
                     hd.total_seqs <= (uint64_t)hd.total_entries * (IX_STRIDE + 1) && hd.total_seqs <= seq_cap &&
                     ix_entries_at(n_blocks, chunks_per_block) + (uint64_t)hd.total_entries * sizeof(IxEntry) <= ix_size;

@@ -147,7 +147,7 @@ lz4f_mi355x_engine::~lz4f_mi355x_engine()
     (void)hipSetDevice(device);
     (void)hipStreamSynchronize((hipStream_t)stream);
     desc.release(); seqcnt.release(); selfix.release(); selfcnt.release(); postab.release(); pdbuf.release();
-    info.release(); recs.release(); e1_scratch.release(); walkbuf.release(); table.release(); blk_bytes.release(); res.release(); bad.release();
+    info.release(); recs.release(); e1_scratch.release(); walkbuf.release(); ixtmp.release(); table.release(); blk_bytes.release(); res.release(); bad.release();
     d_in.release(); d_out.release();
     h_in.release(); h_out.release(); h_small.release();
     for (int i = 0; i < 20; i++) if (ev[i]) (void)hipEventDestroy((hipEvent_t)ev[i]);
@@ -189,7 +189,18 @@ extern "C" __attribute__((visibility("default"))) int lz4f_mi355x_debug_prof(uns
 
 size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst, uint64_t dst_cap,
                                            lz4f_mi355x_result* d_res, lz4f_mi355x_block* d_table, void* d_index, size_t index_cap)
-{
+{    // in-band: the index is made in the engine's own buffer and copied, with the block list, into a skippable frame behind the
+    // LZ4 frame (frame_dev.cuh: the trailer)
+    const bool inband = d_index == nullptr && index_cap == LZ4F_MI355X_INBAND;
+    if (inband) {
+        const size_t bsz = j.block_size, nb_ = (size_t)((j.src_size - j.first_off + bsz - 1) / bsz);
+        const uint32_t ch_ = pick_chunk_size(j.block_size);
+        index_cap = ix_entries_at((uint32_t)nb_, j.block_size / ch_) + ix_typical_entries(j.src_size - j.first_off, (uint32_t)(nb_ * (j.block_size / ch_))) * sizeof(IxEntry) + 64;
+        if (ixtmp.ensure(index_cap + 64) || res.ensure(sizeof(ResultRec) + sizeof(TrailerPlan) + 64)) return make_err(LZ4F_ERROR_allocation_failed);
+        d_index = ixtmp.p;
+        if (((uintptr_t)d_dst & 15) != 0) { set_last_error("in-band index: the frame buffer must be 16-byte aligned"); return make_err(LZ4F_ERROR_GENERIC); }
+    }
+
     HIP_TRY(hipSetDevice(device));
     hipStream_t st = (hipStream_t)stream;
     EncGeom g;
@@ -212,7 +223,8 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     if (recs.ensure((size_t)(g.n_chunks + 1) * g.max_rec_per_chunk * 8)) return make_err(LZ4F_ERROR_allocation_failed);
     if (blk_bytes.ensure((size_t)(g.n_blocks + 1) * 4)) return make_err(LZ4F_ERROR_allocation_failed);
     if (!d_table) { if (table.ensure((size_t)(g.n_blocks + 1) * sizeof(BlockOut))) return make_err(LZ4F_ERROR_allocation_failed); d_table = (lz4f_mi355x_block*)table.p; }
-    if (!d_res) { if (res.ensure(sizeof(ResultRec))) return make_err(LZ4F_ERROR_allocation_failed); d_res = (lz4f_mi355x_result*)res.p; }
+    if (res.ensure(sizeof(ResultRec) + sizeof(TrailerPlan) + 64)) return make_err(LZ4F_ERROR_allocation_failed);
+    if (!d_res) d_res = (lz4f_mi355x_result*)res.p;
 
     constexpr int W = 4;
     for (int i = 0; i < 4; i++) ev_used[i] = false;
@@ -264,6 +276,12 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
             tick(3, true);
         }
     }
+    if (inband && g.n_blocks) {
+        TrailerPlan* plan = (TrailerPlan*)((uint8_t*)res.p + sizeof(ResultRec) + 32);
+        hipLaunchKernelGGL(k_trailer_plan, dim3(1), dim3(64), 0, st, d_dst, dst_cap, (ResultRec*)d_res, g.n_blocks, (const void*)d_index,
+                           (uint64_t)ix_entries_at(g.n_blocks, g.chunks_per_block), plan);
+        hipLaunchKernelGGL(k_trailer_copy, dim3(256), dim3(256), 0, st, d_dst, (const TrailerPlan*)plan, (const BlockOut*)d_table, g.n_blocks, (const void*)d_index);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -294,6 +312,15 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         // once when that has delivered, and walks the list itself otherwise (big blocks: a few hundred hops, and one in 2^9
         // byte positions would be a candidate)
         const uint32_t* walked = nullptr;
+        if (j.hint_list && j.hint_n <= n_max) {
+            // the frame's own trailer says where the size words are: checked link by link like the parallel walk's candidates
+            if (walkbuf.ensure(256)) return make_err(LZ4F_ERROR_allocation_failed);
+            WalkState* ws = (WalkState*)walkbuf.p;
+            hipLaunchKernelGGL(k_walk_head, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, ws, j.hint_n);
+            hipLaunchKernelGGL(k_walk_link, dim3(std::min<uint32_t>((j.hint_n + 255) / 256, 4096u)), dim3(256), 0, st, j.d_frame, j.frame_cap, j.dst_cap, ws, j.hint_list, tbl, n_max);
+            hipLaunchKernelGGL(k_walk_verdict, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, j.dst_cap, ws, j.hint_list, n_max, (ResultRec*)d_res);
+            walked = &ws->done;
+        } else
         if (j.block_size <= (256u << 10) && j.frame_cap >= (1u << 20) && !getenv("LZ4F_MI355X_SERIAL_WALK")) {
             const uint32_t n_chunks = (uint32_t)((j.frame_cap + WK_CHUNK - 1) / WK_CHUNK);
             const size_t list_cap = (size_t)n_max + 1024;
@@ -393,6 +420,9 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             // kernels, and the next one sizes from that - the device checks that the workspace is big enough for the index it
             // actually gets (k_check_index) and otherwise hands the call to the generic decoder.
             const uint32_t chunk = pick_chunk_size(j.block_size), cpb = j.block_size / chunk;
+            // (an index out of the frame's trailer is laid out for the block count the trailer names; the table and the generic
+            // kernels keep the caller's upper bound - if the walk finds another count, the index is dropped on the device)
+            const uint32_t n_ix = (j.hint_list && j.hint_n <= n_max) ? j.hint_n : n_max;
             if (h_ix.ensure(64)) return make_err(LZ4F_ERROR_allocation_failed);
             if (!ix_ev) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ix_ev = e; }
             IxHeader hd; memset(&hd, 0, sizeof(hd));
@@ -423,12 +453,12 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 if (j.linked) if (const char* gs = getenv("LZ4F_MI355X_CHAIN_GATE")) { const int gv = atoi(gs); if (gv > 0 && gv < (1 << 20)) lk |= (uint32_t)gv << 1; }
                 unsigned long long* iprof = (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr);
                 tick(8, false);
-                hipLaunchKernelGGL(k_check_index, dim3(1), dim3(64), 0, st, (const void*)d_index, (uint64_t)index_size, n_max, cpb, chunk,
-                                   (uint64_t)ix_seq_cap, (uint32_t*)seqcnt.p);
-                uint32_t n_lanes = ix_entries_hint > n_max ? ix_entries_hint : n_max;           // (grid-stride inside: a hint is enough)
+                hipLaunchKernelGGL(k_check_index, dim3(1), dim3(64), 0, st, (const void*)d_index, (uint64_t)index_size, n_ix, cpb, chunk,
+                                   (uint64_t)ix_seq_cap, (uint32_t*)seqcnt.p, (const ResultRec*)d_res);
+                uint32_t n_lanes = ix_entries_hint > n_ix ? ix_entries_hint : n_ix;           // (grid-stride inside: a hint is enough)
                 hipLaunchKernelGGL(k_parse_indexed, dim3((n_lanes + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap,
-                                   (const BlockOut*)tbl, (const void*)d_index, n_max, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, lk, (uint64_t)j.hist0);
-                const uint64_t trace_span = (uint64_t)n_max * j.block_size;            // (the last block may be short)
+                                   (const BlockOut*)tbl, (const void*)d_index, n_ix, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, lk, (uint64_t)j.hist0);
+                const uint64_t trace_span = (uint64_t)n_ix * j.block_size;            // (the last block may be short)
                 const bool trace_can = !getenv("LZ4F_MI355X_NO_TRACE") && !getenv("LZ4F_MI355X_NO_RESOLVE") && (j.block_size & 63u) == 0;
                 // (pointer doubling does ~12 GiB/s on text whatever the framing; hop by hop it is 1.3 GiB/s, which only pays where
                 // there is no block-level parallelism - linked frames; independent blocks then stay with the copier workgroups, 4.8 GiB/s)
@@ -436,23 +466,23 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 uint32_t gate = !trace_can ? 0u : getenv("LZ4F_MI355X_TRACE_ALWAYS") ? 2u : (j.linked || can_double) ? 1u : 0u;
                 if (gate && postab.ensure((size_t)(trace_span >> 6) * 4 + 512 + ((size_t)(trace_span >> IXT_REGION_LOG) + 4) * 4)) gate = 0;      // (no memory for the position table: the copiers do it)
                 if (gate && can_double)                                        // (dense by the sequence density: no need to resolve anything)
-                    hipLaunchKernelGGL(k_dense_gate, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, gate, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, 1u, 1u);
+                    hipLaunchKernelGGL(k_dense_gate, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, gate, (const BlockOut*)tbl, (const ResultRec*)d_res, n_ix, 1u, 1u);
                 uint32_t* dsrc = (uint32_t*)((uint8_t*)desc.p + dsrc_at);
                 if (getenv("LZ4F_MI355X_NO_RESOLVE")) dsrc = nullptr;
                 else
-                    hipLaunchKernelGGL(k_resolve_direct, dim3(n_max, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u), dim3(256), 0, st, d_index, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, (const SeqDesc*)desc.p,
+                    hipLaunchKernelGGL(k_resolve_direct, dim3(n_ix, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u), dim3(256), 0, st, d_index, (const BlockOut*)tbl, (const ResultRec*)d_res, n_ix, (const SeqDesc*)desc.p,
                                        dsrc, (uint32_t*)seqcnt.p, (iprof ? 1u : 0u) | (gate ? 2u : 0u), lk);
                 if (iprof) {                                                   // developer aid: how many matches are direct
                     uint32_t c[8];
                     if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(c, seqcnt.p, 32, hipMemcpyDeviceToHost) == hipSuccess)
                         fprintf(stderr, "indexed: flags %u, matches direct after parse %u, resolved %u, left to the chain %u\n", c[0], c[4], c[5], c[6]);
-                    uint32_t x[6] = {0, 0, 0, 0, 0, 0}; if (hipMemcpy(x, (uint32_t*)seqcnt.p + 10, 24, hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "indexed (linked): %u matches stay on the chain, %u of them reach into the block in front (%u blocks); not resolved because: beyond one block %u, source straddles two runs %u, run-length source %u, hop limit %u\n", x[0], x[1], n_max, x[2], x[3], x[4], x[5]);
+                    uint32_t x[6] = {0, 0, 0, 0, 0, 0}; if (hipMemcpy(x, (uint32_t*)seqcnt.p + 10, 24, hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "indexed (linked): %u matches stay on the chain, %u of them reach into the block in front (%u blocks); not resolved because: beyond one block %u, source straddles two runs %u, run-length source %u, hop limit %u\n", x[0], x[1], n_ix, x[2], x[3], x[4], x[5]);
                 }
                 // dense frames (text): no chain at all, every output byte traced to its literal (see k_trace_copy)
                 {
-                    hipLaunchKernelGGL(k_dense_gate, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, gate, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, 0u, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u);
+                    hipLaunchKernelGGL(k_dense_gate, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, gate, (const BlockOut*)tbl, (const ResultRec*)d_res, n_ix, 0u, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u);
                     if (gate) {
-                        hipLaunchKernelGGL(k_build_postab, dim3(n_max, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u), dim3(256), 0, st, d_index, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max,
+                        hipLaunchKernelGGL(k_build_postab, dim3(n_ix, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u), dim3(256), 0, st, d_index, (const BlockOut*)tbl, (const ResultRec*)d_res, n_ix,
                                            (const SeqDesc*)desc.p, (uint32_t*)postab.p, (uint32_t*)seqcnt.p);
                         const uint64_t n_thr = (trace_span + IXT_TB - 1) / IXT_TB;
                         // if the last index seen here was of a dense stream (the device decides about THIS one, but the
@@ -462,18 +492,18 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                             uint32_t* remaining = (uint32_t*)((uint8_t*)pdbuf.p + (((size_t)trace_span * 4 + 255) & ~(size_t)255));
                             if (hipMemsetAsync(remaining, 0, (IXP_ROUNDS + 1) * IXP_STRIPES * 4, st) != hipSuccess) return make_err(LZ4F_ERROR_GENERIC);
                             hipLaunchKernelGGL(k_pd_init, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, (const BlockOut*)tbl,
-                                               (const ResultRec*)d_res, n_max, d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (const uint32_t*)postab.p, (uint32_t*)seqcnt.p,
+                                               (const ResultRec*)d_res, n_ix, d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (const uint32_t*)postab.p, (uint32_t*)seqcnt.p,
                                                lk & 1u, (uint32_t)j.block_size, (uint64_t)j.hist0, (uint32_t*)pdbuf.p, remaining);
                             for (uint32_t r = 1; r <= IXP_ROUNDS; r++)
                                 hipLaunchKernelGGL(k_pd_round, dim3((uint32_t)((trace_span / 4 + 255) / 256)), dim3(256), 0, st, j.d_dst, (uint32_t*)pdbuf.p, (const BlockOut*)tbl,
-                                                   (const ResultRec*)d_res, n_max, r, remaining, (uint32_t*)seqcnt.p);
+                                                   (const ResultRec*)d_res, n_ix, r, remaining, (uint32_t*)seqcnt.p);
                             hipLaunchKernelGGL(k_pd_verdict, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, (const uint32_t*)remaining);
                             if (iprof) { static uint32_t t[(IXP_ROUNDS + 1) * IXP_STRIPES]; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(t, remaining, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) { fprintf(stderr, "doubling: bytes open after each round:"); for (uint32_t r = 0; r <= IXP_ROUNDS; r++) { uint64_t sum = 0; for (uint32_t q = 0; q < IXP_STRIPES; q++) sum += t[r * IXP_STRIPES + q]; fprintf(stderr, " %llu", (unsigned long long)sum); } fprintf(stderr, "\n"); } }
                         } else {
                         uint32_t* region_cnt = (uint32_t*)((uint8_t*)postab.p + (((size_t)(trace_span >> 6) * 4 + 255) & ~(size_t)255));
                         if (hipMemsetAsync(region_cnt, 0, ((size_t)(trace_span >> IXT_REGION_LOG) + 2) * 4, st) != hipSuccess) return make_err(LZ4F_ERROR_GENERIC);
                         hipLaunchKernelGGL(k_trace_copy, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, (const BlockOut*)tbl,
-                                           (const ResultRec*)d_res, n_max, d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (const uint32_t*)postab.p, (uint32_t*)seqcnt.p,
+                                           (const ResultRec*)d_res, n_ix, d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (const uint32_t*)postab.p, (uint32_t*)seqcnt.p,
                                            lk & 1u, (uint32_t)j.block_size, (uint64_t)j.hist0, region_cnt, iprof ? 1u : 0u);
                         if (iprof) { uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(t, (uint32_t*)seqcnt.p + 24, 32, hipMemcpyDeviceToHost) == hipSuccess && t[0]) fprintf(stderr, "traced: %llu turns for %u pieces (%u read from the output), deepest thread %u turns\n", (unsigned long long)t[2] | ((unsigned long long)t[3] << 32), t[4], t[5], t[6]); }
                         }
@@ -483,12 +513,12 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 tick(9, false);
                 // (linked frames of small blocks: a workgroup takes a group of consecutive blocks - see k_copy_indexed)
                 const uint32_t group = (j.linked && j.block_size < (1u << 20) && !getenv("LZ4F_MI355X_NO_GROUPS")) ? (1u << 20) / j.block_size : 1u;
-                const uint32_t n_wg = (n_max + group - 1) / group;
+                const uint32_t n_wg = (n_ix + group - 1) / group;
                 if (j.block_size <= (1u << 20))
-                    hipLaunchKernelGGL(k_copy_indexed<FzCfg<4>>, dim3(n_wg), dim3(64 * 4), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_max,
+                    hipLaunchKernelGGL(k_copy_indexed<FzCfg<4>>, dim3(n_wg), dim3(64 * 4), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_ix,
                                        d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done, group, (uint64_t)j.hist0);
                 else
-                    hipLaunchKernelGGL(k_copy_indexed<FzCfg<8>>, dim3(n_wg), dim3(64 * 8), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_max,
+                    hipLaunchKernelGGL(k_copy_indexed<FzCfg<8>>, dim3(n_wg), dim3(64 * 8), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_ix,
                                        d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done, group, (uint64_t)j.hist0);
                 tick(9, true);
                 if (iprof && j.linked) { uint32_t y[4] = {0, 0, 0, 0}; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(y, (uint32_t*)seqcnt.p + 20, 16, hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "indexed (linked): blocks that found the block in front at state 3: %u (of those, had to wait for all of it: %u); blocks with set-aside matches %u (block in front already done: %u)\n", y[0], y[1], y[2], y[3]); }
@@ -907,11 +937,19 @@ size_t lz4f_mi355x_dev_index_size(size_t srcSize, const LZ4F_preferences_t* pref
     return ix_entries_at(nb, cpb) + ix_typical_entries(srcSize, nb * cpb) * sizeof(IxEntry);
 }
 
+size_t lz4f_mi355x_trailer_bound(size_t srcSize, const LZ4F_preferences_t* prefs)
+{
+    size_t bs = block_size_of(prefs ? prefs->frameInfo.blockSizeID : 0);
+    if (!bs) bs = 65536;
+    return lz4f_mi355x_dev_index_size(srcSize, prefs) + ((srcSize + bs - 1) / bs + 2) * 8 + 128;
+}
+
 size_t lz4f_mi355x_dev_compressFrameIndexed(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize,
                                             const LZ4F_preferences_t* prefs, lz4f_mi355x_result* d_result, lz4f_mi355x_block* d_table, void* d_index,
                                             size_t indexCapacity)
 {
-    if (!e || !d_table || !d_result) return make_err(LZ4F_ERROR_GENERIC);
+    const bool inband = d_index == nullptr && indexCapacity == LZ4F_MI355X_INBAND;
+    if (!e || (!inband && (!d_table || !d_result))) return make_err(LZ4F_ERROR_GENERIC);
     LZ4F_preferences_t p; memset(&p, 0, sizeof(p));
     if (prefs) p = *prefs;
     if (p.frameInfo.blockSizeID == 0) p.frameInfo.blockSizeID = LZ4F_max64KB;
@@ -924,7 +962,7 @@ size_t lz4f_mi355x_dev_compressFrameIndexed(lz4f_mi355x_engine* e, void* d_dst, 
     j.d_src = (const uint8_t*)d_src; j.src_size = srcSize; j.first_off = 0; j.block_size = (uint32_t)bs;
     j.linked = p.frameInfo.blockMode == LZ4F_blockLinked; j.block_checksum = p.frameInfo.blockChecksumFlag != 0; j.endmark = true;
     j.header_size = (uint32_t)write_frame_header(j.header, p);
-    return e->launch_compress(j, (uint8_t*)d_dst, dstCapacity, d_result, d_table, d_index, d_index ? indexCapacity : 0);
+    return e->launch_compress(j, (uint8_t*)d_dst, dstCapacity, d_result, d_table, d_index, inband ? LZ4F_MI355X_INBAND : (d_index ? indexCapacity : 0));
 }
 
 size_t lz4f_mi355x_dev_decompressBlocksIndexed(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_frame, size_t frameCapacity,
@@ -950,7 +988,10 @@ size_t lz4f_mi355x_dev_decompressFrame(lz4f_mi355x_engine* e, void* d_dst, size_
     uint8_t hdr[32]; memset(hdr, 0, sizeof(hdr));
     const size_t peek = frameCapacity < 19 ? frameCapacity : 19;
     if (peek < 7) return make_err(LZ4F_ERROR_frameHeader_incomplete);
+    TrailerFoot foot; memset(&foot, 0, sizeof(foot));              // the stream's last 16 bytes: this library's trailer, if it is one
+    const bool may_trail = frameCapacity >= 64 && ((uintptr_t)d_frame & 15) == 0 && !getenv("LZ4F_MI355X_NO_TRAILER");
     if (hipMemcpyAsync(hdr, d_frame, peek, hipMemcpyDeviceToHost, (hipStream_t)e->stream) != hipSuccess ||
+        (may_trail && hipMemcpyAsync(&foot, (const uint8_t*)d_frame + frameCapacity - sizeof(foot), sizeof(foot), hipMemcpyDeviceToHost, (hipStream_t)e->stream) != hipSuccess) ||
         hipStreamSynchronize((hipStream_t)e->stream) != hipSuccess) { set_last_error("header peek failed"); return make_err(LZ4F_ERROR_GENERIC); }
     lz4f_mi355x_engine::DecompressJob j; memset(&j, 0, sizeof(j));
     j.d_frame = (const uint8_t*)d_frame; j.frame_cap = frameCapacity; j.d_dst = (uint8_t*)d_dst; j.dst_cap = dstCapacity; j.hist0 = 0;
@@ -966,6 +1007,16 @@ size_t lz4f_mi355x_dev_decompressFrame(lz4f_mi355x_engine* e, void* d_dst, size_
         uint64_t mb = by_dst < by_src ? by_dst : by_src;
         if (mb > 0x7FFFFFFFull) mb = 0x7FFFFFFFull;
         j.max_blocks = (uint32_t)mb;
+        // a trailer (frame_dev.cuh): where it says the size words are, and the sequence index.  Only as hints: the kernels check both
+        if (may_trail && foot.magic == TR_FOOT && foot.n_blocks && foot.n_blocks <= j.max_blocks && foot.total >= 8 + sizeof(foot) && foot.total <= frameCapacity - hs) {
+            const uint64_t at = frameCapacity - foot.total;
+            const uint64_t list_at = (at + 8 + 15) & ~(uint64_t)15, n_list = ((uint64_t)foot.n_blocks + 1) & ~1ull, ix_at = list_at + n_list * 8;
+            if (ix_at + sizeof(foot) <= frameCapacity) {
+                j.hint_list = (const uint64_t*)((const uint8_t*)d_frame + list_at); j.hint_n = foot.n_blocks;      // (frame_cap stays the whole buffer: `at` is a claim)
+                const uint64_t ix_bytes = frameCapacity - sizeof(foot) - ix_at;
+                if (ix_bytes >= sizeof(IxHeader) && !j.linked) { j.d_index = (void*)((const uint8_t*)d_frame + ix_at); j.index_size = (size_t)ix_bytes; }
+            }
+        }
     }
     return e->launch_decompress(j, d_result);
 }

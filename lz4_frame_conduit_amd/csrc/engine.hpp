@@ -54,6 +54,7 @@ struct lz4f_mi355x_engine {
     void* stream = nullptr;        // hipStream_t
     bool  own_stream = false;
     lz4f::DevBuf info, recs, table, blk_bytes, res, bad;   // workspace of the block kernels
+    lz4f::DevBuf ixtmp;                                    // in-band index: made here, copied into the frame's trailer
     lz4f::DevBuf walkbuf;                                  // frames without a block table: the parallel walk's candidates
     lz4f::DevBuf e1_scratch;                               // pass E1: per workgroup, the slice lists of the tile it is searching
     lz4f::DevBuf selfix, selfcnt;                          // linked frames without an index: the one made here, and its per-block counts
@@ -87,6 +88,7 @@ struct lz4f_mi355x_engine {
         const lz4f_mi355x_block* d_table; uint32_t n_blocks;     // when d_table != null the walk is skipped
         bool table_in_place;                                     // the engine's own table already holds n_blocks entries
         uint32_t max_blocks;                                     // grid bound when walking
+        const uint64_t* hint_list; uint32_t hint_n;              // from the frame's trailer: where the size words should be (checked on the device)
     };
     size_t launch_decompress(const DecompressJob& j, lz4f_mi355x_result* d_res);
     size_t sync();

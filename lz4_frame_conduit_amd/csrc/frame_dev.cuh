@@ -223,12 +223,12 @@ __device__ __forceinline__ uint32_t walk_header(const uint8_t* __restrict__ fram
     return 0;
 }
 
-__global__ void k_walk_head(const uint8_t* __restrict__ frame, uint64_t frame_cap, WalkState* __restrict__ ws)
+__global__ void k_walk_head(const uint8_t* __restrict__ frame, uint64_t frame_cap, WalkState* __restrict__ ws, uint32_t preset_total = 0)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint32_t hsize = 0, bs = 0, bck = 0, flg = 0; uint64_t content = 0;
     const uint32_t st = walk_header(frame, frame_cap, hsize, bs, bck, flg, content);
-    ws->done = 0; ws->overflow = 0; ws->total = 0; ws->first_end = 0xFFFFFFFFu; ws->first_break = 0xFFFFFFFFu;
+    ws->done = 0; ws->overflow = 0; ws->total = preset_total; ws->first_end = 0xFFFFFFFFu; ws->first_break = 0xFFFFFFFFu;
     ws->hsize = hsize; ws->bs = bs; ws->bck = bck; ws->flg = flg; ws->content = content;
     ws->head_ok = st == 0 ? 1u : 0u;                                  // (a bad header: k_walk_frame gives the verdict)
 }
@@ -236,7 +236,7 @@ __global__ void k_walk_head(const uint8_t* __restrict__ frame, uint64_t frame_ca
 // does the word at `pos` look like a size word whose block fits the frame?  -> position of the next word
 __device__ __forceinline__ bool walk_step(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint32_t bs, uint32_t bck, uint64_t pos, uint64_t& next, bool& end)
 {
-    if (frame_cap - pos < 4) return false;
+    if (pos > frame_cap || frame_cap - pos < 4) return false;       // (positions out of a trailer are anybody's numbers)
     const uint32_t w = *(const u32_ua*)(frame + pos);
     end = w == 0;
     if (end) { next = pos + 4; return true; }
@@ -419,6 +419,58 @@ __global__ void k_walk_verdict(const uint8_t* __restrict__ frame, uint64_t frame
     ResultRec r; r.size = ws->content; r.consumed = pos; r.status = ST_OK; r.n_blocks = n; r.first_bad_block = 0xFFFFFFFFu; r.flags = flg;
     *res = r;
     ws->done = 1;
+}
+
+// ------------------------------- the frame's trailer (in-band block list + sequence index) ------
+// What this library's own decoder can use - where every block's size word sits, and the compressor's sequence index (encode.cuh) -
+// travels IN the byte stream, as a skippable frame (magic 0x184D2A5E) right behind the LZ4 frame: liblz4, the `lz4` tool and
+// the reference's decompress conduit skip or never reach it, this decoder finds it from its last 16 bytes.
+//   frame | 5E 2A 4D 18 | u32 size | pad to 16 | u64 word_pos[n_blocks (+1 to even)] | index (IxHeader ... entries) or nothing |
+//         | footer: u32 'LZIX', u32 n_blocks, u64 trailer bytes (from the magic on)
+// Nothing in it is trusted: the positions are accepted only if they are the chain the size words themselves form (k_walk_link /
+// k_walk_verdict, as for the candidates of the parallel walk), the index only as far as k_parse_indexed can follow it in the payload.
+constexpr uint32_t TR_MAGIC = 0x184D2A5Eu, TR_FOOT = 0x58495A4Cu;
+struct TrailerFoot { uint32_t magic, n_blocks; uint64_t total; };
+struct TrailerPlan { uint64_t at, list_at, ix_at, ix_bytes, total; uint32_t n_list, ok; };
+
+__global__ void k_trailer_plan(uint8_t* __restrict__ dst, uint64_t dst_cap, ResultRec* __restrict__ res, uint32_t n_blocks, const void* __restrict__ ix,
+                               uint64_t ix_fixed, TrailerPlan* __restrict__ plan)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    TrailerPlan p; memset(&p, 0, sizeof(p));
+    if (res->status == ST_OK && n_blocks) {
+        const uint64_t F = res->size;
+        const IxHeader* hd = (const IxHeader*)ix;
+        const bool with_ix = ix && hd->magic == IX_MAGIC && hd->pad0 == 0;      // (pad0: linked frames; their decoder indexes them itself)
+        p.at = F;
+        p.list_at = (F + 8 + 15) & ~(uint64_t)15;
+        p.n_list = (n_blocks + 1) & ~1u;
+        p.ix_at = p.list_at + (uint64_t)p.n_list * 8;
+        p.ix_bytes = with_ix ? (ix_fixed + (uint64_t)hd->total_entries * sizeof(IxEntry) + 15) & ~(uint64_t)15 : 0;
+        p.total = p.ix_at + p.ix_bytes + sizeof(TrailerFoot) - F;
+        p.ok = (F + p.total <= dst_cap && p.total - 8 < 0xFFFFFFFFull) ? 1u : 0u;
+        if (p.ok) {
+            uint8_t* t = dst + F;
+            const uint32_t sz = (uint32_t)(p.total - 8);
+            t[0] = 0x5E; t[1] = 0x2A; t[2] = 0x4D; t[3] = 0x18; t[4] = (uint8_t)sz; t[5] = (uint8_t)(sz >> 8); t[6] = (uint8_t)(sz >> 16); t[7] = (uint8_t)(sz >> 24);
+            for (uint64_t q = F + 8; q < p.list_at; q++) dst[q] = 0;
+            TrailerFoot f{TR_FOOT, n_blocks, p.total};
+            memcpy(dst + p.ix_at + p.ix_bytes, &f, sizeof(f));
+            res->size = F + p.total;
+        }
+    }
+    *plan = p;
+}
+__global__ __launch_bounds__(256) void k_trailer_copy(uint8_t* __restrict__ dst, const TrailerPlan* __restrict__ plan, const BlockOut* __restrict__ table,
+                                                      uint32_t n_blocks, const void* __restrict__ ix)
+{
+    const TrailerPlan p = *plan;
+    if (!p.ok) return;
+    const uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x, step = (uint64_t)gridDim.x * 256;
+    uint64_t* list = (uint64_t*)(dst + p.list_at);                   // (16-byte aligned within the frame buffer; the caller's buffer is)
+    for (uint64_t i = t; i < p.n_list; i += step) list[i] = i < n_blocks ? table[i].src_off - 4 : 0;
+    const uint4* s = (const uint4*)ix; uint4* d = (uint4*)(dst + p.ix_at);
+    for (uint64_t i = t; i < p.ix_bytes / 16; i += step) d[i] = s[i];
 }
 
 // ------------------------------- block decode ---------------------------------------------------

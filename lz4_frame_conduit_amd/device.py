@@ -64,11 +64,23 @@ class Engine:
     def frame_bound(self, n: int, prefs: Preferences) -> int:
         return _chk(self.L, self.L.lz4f_mi355x_compressFrameBound(n, ctypes.byref(prefs)))
 
+    INBAND = (1 << 64) - 1
+
+    def frame_bound_inband(self, n: int, prefs: Preferences) -> int:
+        """Room for a frame with its trailer (block list + sequence index in a skippable frame behind it)."""
+        return self.frame_bound(n, prefs) + int(self.L.lz4f_mi355x_trailer_bound(n, ctypes.byref(prefs)))
+
     def compress_async(self, src: torch.Tensor, dst: torch.Tensor, prefs: Preferences, table: "torch.Tensor | None" = None,
-                       index: "torch.Tensor | None" = None):
+                       index: "torch.Tensor | None" = None, inband: bool = False):
         """Enqueue src -> one frame in dst.  Returns nothing; call result() after a sync.
-        With `index` (new_index) the compressor also leaves its sequence index there for decompress_blocks_async."""
+        With `index` (new_index) the compressor also leaves its sequence index there for decompress_blocks_async.
+        With `inband` the index and the block list go into the stream itself (a skippable frame behind the LZ4 frame, counted in
+        result().size): decompress_frame_async finds them there."""
         assert src.dtype == torch.uint8 and dst.dtype == torch.uint8 and src.is_cuda and dst.is_cuda
+        if inband:
+            _chk(self.L, self.L.lz4f_mi355x_dev_compressFrameIndexed(self.h, dst.data_ptr(), dst.numel(), src.data_ptr(), src.numel(), ctypes.byref(prefs),
+                                                                    self._res.data_ptr(), table.data_ptr() if table is not None else None, None, self.INBAND))
+            return
         if index is not None:
             assert table is not None and index.dtype == torch.uint8 and index.is_cuda
             _chk(self.L, self.L.lz4f_mi355x_dev_compressFrameIndexed(self.h, dst.data_ptr(), dst.numel(), src.data_ptr(), src.numel(), ctypes.byref(prefs),

@@ -804,4 +804,47 @@ def test_parallel_walk_of_device_frames(L, monkeypatch):
     eng.close()
 
 
-
+@pytest.mark.gpu
+def test_inband_trailer_interop_and_robustness(L):
+    """The in-band index: a skippable frame behind the LZ4 frame.  liblz4 (the oracle), the reference's decompress conduit and the
+    batched conduit decode the stream to the input; this library's device decoder uses the trailer (no walk, indexed parse) and
+    gives the same bytes - also when the trailer is damaged, truncated, or lies about the frame."""
+    import torch
+    from lz4_frame_conduit_amd.device import Engine
+    eng = Engine(0)
+    rng = np.random.default_rng(12)
+    for name, data, kw in (("synth50", datagen.synth50(24 << 20, 9), dict(bsid=7, indep=1)), ("synth50/1M", datagen.synth50(8 << 20, 10), dict(bsid=6, indep=1, bck=1)),
+                           ("text", datagen.synth_text(6 << 20, 4), dict(bsid=5, indep=1)), ("linked", datagen.synth50(4 << 20, 11), dict(bsid=4, indep=0))):
+        src = torch.from_numpy(data).cuda()
+        p = prefs_of(kw)
+        frame = torch.empty(eng.frame_bound_inband(src.numel(), p), dtype=torch.uint8, device="cuda")
+        eng.compress_async(src, frame, p, inband=True)
+        r = eng.result()
+        stream = frame[:r.size].cpu().numpy().tobytes()
+        out, used = oracle.decompress_frame(stream, cap=len(data) + 64)                    # liblz4's decoder: the frame, then what is left is a skippable frame
+        assert out == data.tobytes() and used < len(stream), name
+        rest = stream[used:]
+        assert rest[:4] == bytes.fromhex("5e2a4d18") and int.from_bytes(rest[4:8], "little") == len(rest) - 8, name
+        assert b"".join(conduit.decompress([stream])) == data.tobytes(), name            # Conduit.hsc:598: stops at the EndMark
+        assert b"".join(conduit.decompressBatched([stream[:100000], stream[100000:]])) == data.tobytes(), name
+        back = torch.zeros_like(src)
+        eng.decompress_frame_async(frame, int(r.size), back)
+        r2 = eng.result()
+        assert r2.size == src.numel() and r2.consumed == used and torch.equal(back, src), name
+        # damage: bytes of the block list, of the index, of the footer; a footer that names another block count; a cut trailer
+        tr = len(stream) - used
+        for trial in range(10):
+            bad = bytearray(stream)
+            if trial < 6:
+                for _ in range(1 + trial): bad[used + int(rng.integers(8, tr))] ^= int(rng.integers(1, 256))
+            elif trial == 6: bad[-12:-8] = (int.from_bytes(bad[-12:-8], "little") + 1).to_bytes(4, "little")
+            elif trial == 7: bad[-8:] = (int.from_bytes(bad[-8:], "little") - 16).to_bytes(8, "little")
+            elif trial == 8: bad = bad[:len(bad) - 5000] if tr > 6000 else bad[:-8]
+            else: bad[used + 16:used + 16 + 64] = bytes(64)
+            dev = torch.zeros(len(bad) + 32, dtype=torch.uint8, device="cuda")
+            dev[:len(bad)] = torch.from_numpy(np.frombuffer(bytes(bad), dtype=np.uint8).copy()).cuda()
+            back.zero_()
+            eng.decompress_frame_async(dev, len(bad), back)
+            r3 = eng.result()
+            assert r3.size == src.numel() and torch.equal(back, src), (name, trial)
+    eng.close()

@@ -13,7 +13,9 @@ else: src = synth50_device(n, 1234)
 eng = Engine(0); p = conduit.make_preferences(blockSizeID=bsid, blockMode=1)
 frame = torch.empty(eng.frame_bound(n, p), dtype=torch.uint8, device="cuda"); back = torch.empty_like(src)
 eng.set_timing(True)
-eng.compress_async(src, frame, p); r = eng.result()
+inband = os.environ.get("INBAND") == "1"
+if inband: frame = torch.empty(eng.frame_bound_inband(n, p), dtype=torch.uint8, device="cuda")
+eng.compress_async(src, frame, p, inband=inband); r = eng.result()
 for it in range(3):
     back.zero_()
     eng.decompress_frame_async(frame, int(r.size), back); r2 = eng.result(); t = eng.get_timing()
