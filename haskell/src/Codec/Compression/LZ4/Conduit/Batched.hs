@@ -1,0 +1,253 @@
+{-# LANGUAGE ForeignFunctionInterface #-}
+{-# LANGUAGE LambdaCase #-}
+{-# LANGUAGE ScopedTypeVariables #-}
+
+{-|
+Module      : Codec.Compression.LZ4.Conduit.Batched
+Description : Conduits that hand the LZ4 frame codec many blocks per call (for liblz4f_mi355x).
+
+An addition to nh2/lz4-frame-conduit (SURVEY.md 8f, row N2).  The conduits of
+"Codec.Compression.LZ4.Conduit" call @LZ4F_compressUpdate@ once per 16 KiB slice
+(@Conduit.hsc:452-469@) and @LZ4F_decompress@ once per 16 KiB of output (@Conduit.hsc:638-669@) and
+can only pass @lz4DefaultPreferences@ (@Conduit.hsc:340-347@).  Against @liblz4f_mi355x@ that is
+correct but bound by PCIe round trips and kernel launches: one 64 KiB block per four calls.  The
+conduits here give the library what it needs to be fast - caller-chosen preferences and hundreds
+of blocks per call - through the same C ABI:
+
+* 'compressWithPreferences' - the reference's slice loop with the caller's 'Preferences';
+* 'compressBatched' - gathers @batchBytes@ of input in a page-locked buffer, then ONE
+  @LZ4F_compressUpdate@ (a single call may create many blocks, @Conduit.hsc:326-333@);
+* 'decompressBatched' - gathers the stream and decodes frame by frame through
+  @lz4f_mi355x_decompressFrameTo@, which yields the output slab by slab.
+
+The C++ mirror of exactly these three drivers is @lz4_frame_conduit_amd/csrc/conduit.cpp@; it is what
+@tests/test_gpu_parity.py@ runs (@test_conduits_on_reference_test_inputs@, @test_batched_decoder_walks_whole_streams@).
+THIS FILE HAS NOT BEEN COMPILED: the build image has no GHC.  It uses plain @foreign import ccall@
+(no inline-c), so it needs nothing beyond what the package already depends on.
+-}
+module Codec.Compression.LZ4.Conduit.Batched
+  ( compressWithPreferences
+  , compressBatched
+  , decompressBatched
+  , defaultBatchBytes
+  ) where
+
+import           Control.Concurrent (forkIO)
+import           Control.Concurrent.MVar (MVar, newEmptyMVar, putMVar, takeMVar)
+import           Control.Monad (unless, void, when)
+import           Control.Monad.IO.Class (liftIO)
+import           Control.Monad.IO.Unlift (MonadUnliftIO)
+import           Control.Monad.Trans.Resource (MonadResource)
+import           Data.Bits (shiftL, (.&.), (.|.))
+import           Data.ByteString (ByteString, packCStringLen)
+import qualified Data.ByteString as BS
+import           Data.ByteString.Unsafe (unsafePackCString, unsafeUseAsCStringLen)
+import           Data.Conduit
+import           Data.IORef (newIORef, readIORef, writeIORef)
+import           Data.Word (Word32)
+import           Foreign.C.String (CString)
+import           Foreign.C.Types (CChar, CSize (..), CUInt (..))
+import           Foreign.Marshal.Alloc (alloca, free, mallocBytes)
+import           Foreign.Marshal.Utils (copyBytes, new)
+import           Foreign.Ptr (FunPtr, Ptr, freeHaskellFunPtr, nullPtr, plusPtr)
+import           Foreign.Storable (peek)
+import           UnliftIO.Exception (throwString)
+
+import           Codec.Compression.LZ4.Conduit (BlockSizeID (..), FrameInfo (..), Preferences (..))
+import           Codec.Compression.LZ4.CTypes (LZ4F_cctx)
+
+
+-- * The C ABI (include/lz4f_mi355x.h).  Part 1 names are liblz4's; Part 2 are the library's own.
+
+foreign import ccall unsafe "LZ4F_isError"                 c_isError :: CSize -> IO CUInt
+foreign import ccall unsafe "LZ4F_getErrorName"            c_getErrorName :: CSize -> IO CString
+foreign import ccall safe   "LZ4F_createCompressionContext" c_createCctx :: Ptr (Ptr LZ4F_cctx) -> CUInt -> IO CSize
+foreign import ccall safe   "LZ4F_freeCompressionContext"  c_freeCctx :: Ptr LZ4F_cctx -> IO CSize
+foreign import ccall safe   "LZ4F_compressBegin"           c_compressBegin :: Ptr LZ4F_cctx -> Ptr CChar -> CSize -> Ptr Preferences -> IO CSize
+foreign import ccall unsafe "LZ4F_compressBound"           c_compressBound :: CSize -> Ptr Preferences -> IO CSize
+foreign import ccall safe   "LZ4F_compressUpdate"          c_compressUpdate :: Ptr LZ4F_cctx -> Ptr CChar -> CSize -> Ptr CChar -> CSize -> Ptr () -> IO CSize
+foreign import ccall safe   "LZ4F_compressEnd"             c_compressEnd :: Ptr LZ4F_cctx -> Ptr CChar -> CSize -> Ptr () -> IO CSize
+-- page-locked host memory: the bulk path copies straight out of / into it (no staging copy)
+foreign import ccall safe   "lz4f_mi355x_host_alloc"       c_hostAlloc :: CSize -> IO (Ptr CChar)
+foreign import ccall safe   "lz4f_mi355x_host_free"        c_hostFree :: Ptr CChar -> IO ()
+-- size_t lz4f_mi355x_decompressFrameTo(yield, user, src, srcSize, &consumed): one whole frame, output handed to `yield` in order
+type YieldFn = Ptr () -> Ptr CChar -> CSize -> IO ()
+foreign import ccall safe   "lz4f_mi355x_decompressFrameTo" c_decompressFrameTo :: FunPtr YieldFn -> Ptr () -> Ptr CChar -> CSize -> Ptr CSize -> IO CSize
+foreign import ccall "wrapper" mkYieldFn :: YieldFn -> IO (FunPtr YieldFn)
+
+
+-- | Same message format as the reference's @handleLz4Error@ (@Conduit.hsc:149-160@).
+checkLz4 :: IO CSize -> IO CSize
+checkLz4 act = do
+  r <- act
+  isErr <- c_isError r
+  when (isErr /= 0) $ do
+    name <- unsafePackCString =<< c_getErrorName r
+    throwString ("lz4frame error: " ++ show name)
+  return r
+
+
+lz4fVersion :: CUInt
+lz4fVersion = 100          -- LZ4F_VERSION
+
+lz4fHeaderSizeMax :: CSize
+lz4fHeaderSizeMax = 19     -- LZ4F_HEADER_SIZE_MAX
+
+-- | 64 MiB: one slab of the library's host pipeline (csrc/pipeline.hip).
+defaultBatchBytes :: Int
+defaultBatchBytes = 64 * 1024 * 1024
+
+
+data CompressState = CompressState
+  { csCtx      :: !(Ptr LZ4F_cctx)
+  , csPrefs    :: !(Ptr Preferences)
+  , csIn       :: !(Ptr CChar)
+  , csOut      :: !(Ptr CChar)
+  , csOutSize  :: !CSize
+  , csPinned   :: !Bool
+  }
+
+
+-- | The reference's 'compress' (16 KiB slices, one @LZ4F_compressUpdate@ each) with caller-chosen preferences.
+compressWithPreferences :: (MonadUnliftIO m, MonadResource m) => Preferences -> ConduitT ByteString ByteString m ()
+compressWithPreferences = compressGathering False (16 * 1024)
+
+
+-- | Gathers @batchBytes@ of input (rounded up to whole blocks), then one @LZ4F_compressUpdate@: all completed blocks of the
+-- batch are encoded by one pass of the GPU kernels.  The frame is an ordinary LZ4 frame; with linked blocks the context keeps
+-- the 64 KiB of history across batches as liblz4's does.  Memory: the batch and its worst-case output, page-locked.
+compressBatched :: (MonadUnliftIO m, MonadResource m) => Int -> Preferences -> ConduitT ByteString ByteString m ()
+compressBatched batchBytes prefs = compressGathering True (roundUp (max 1 batchBytes)) prefs
+  where
+    blockBytes = case blockSizeID (frameInfo prefs) of
+      LZ4F_max256KB -> 256 * 1024
+      LZ4F_max1MB   -> 1024 * 1024
+      LZ4F_max4MB   -> 4 * 1024 * 1024
+      _             -> 64 * 1024
+    roundUp n = ((n + blockBytes - 1) `div` blockBytes) * blockBytes
+
+
+compressGathering :: forall m . (MonadUnliftIO m, MonadResource m) => Bool -> Int -> Preferences -> ConduitT ByteString ByteString m ()
+compressGathering pinned batch prefs = bracketP acquire release run
+  where
+    allocBuf :: CSize -> IO (Ptr CChar)
+    allocBuf n
+      | pinned = do
+          p <- c_hostAlloc n
+          when (p == nullPtr) $ throwString "lz4frame error: \"ERROR_allocation_failed\""
+          return p
+      | otherwise = mallocBytes (fromIntegral n)
+
+    acquire :: IO CompressState
+    acquire = do
+      ctx <- alloca $ \pp -> do
+        _ <- checkLz4 (c_createCctx pp lz4fVersion)
+        peek pp
+      prefsPtr <- new prefs
+      outSize <- checkLz4 (c_compressBound (fromIntegral batch + lz4fHeaderSizeMax) prefsPtr)
+      inBuf <- allocBuf (fromIntegral batch)
+      outBuf <- allocBuf outSize
+      return (CompressState ctx prefsPtr inBuf outBuf outSize pinned)
+
+    release :: CompressState -> IO ()
+    release s = do
+      void (c_freeCctx (csCtx s))
+      free (csPrefs s)
+      if csPinned s then c_hostFree (csIn s) >> c_hostFree (csOut s) else free (csIn s) >> free (csOut s)
+
+    run :: CompressState -> ConduitT ByteString ByteString m ()
+    run s = do
+      let emit n = when (n > 0) $ yield =<< liftIO (packCStringLen (csOut s, fromIntegral n))
+      -- header (Conduit.hsc:292-296)
+      emit =<< liftIO (checkLz4 (c_compressBegin (csCtx s) (csOut s) (csOutSize s) (csPrefs s)))
+      -- batches
+      let flush used = when (used > 0) $
+            emit =<< liftIO (checkLz4 (c_compressUpdate (csCtx s) (csOut s) (csOutSize s) (csIn s) (fromIntegral used) nullPtr))
+          gather used = await >>= \case
+            Nothing -> flush used
+            Just bs -> place used bs
+          place used bs
+            | BS.null bs = gather used
+            | otherwise = do
+                let (now, later) = BS.splitAt (batch - used) bs
+                liftIO $ unsafeUseAsCStringLen now $ \(p, l) -> copyBytes (csIn s `plusPtr` used) p l
+                let used' = used + BS.length now
+                if used' == batch then flush used' >> place 0 later else place used' later
+      gather 0
+      -- EndMark and content checksum (Conduit.hsc:318-324); srcSize 0 is the bound for LZ4F_compressEnd
+      emit =<< liftIO (checkLz4 (c_compressEnd (csCtx s) (csOut s) (csOutSize s) nullPtr))
+
+
+data Handoff = Chunk !ByteString | Done !CSize !CSize      -- result of the call, bytes of input it consumed
+
+
+-- | Decodes a stream of LZ4 frames through the bulk path: per frame the library walks the size words on the host, keeps slabs of
+-- blocks in flight on the GPU(s) and hands the output over slab by slab (at most one slab waits in the hand-off).  Unlike the
+-- reference's 'decompress' (which stops at the first EndMark and cannot read headers with a dictID) this decodes every frame of
+-- the stream, skips skippable frames and accepts every header the format allows - what calling @LZ4F_decompress@ in a loop does.
+-- The input is gathered first: a frame's blocks cannot be found before its size words are there.
+-- Build with @-threaded@: the C call runs beside the conduit and calls back into Haskell.
+decompressBatched :: forall m . (MonadUnliftIO m, MonadResource m) => ConduitT ByteString ByteString m ()
+decompressBatched = do
+  stream <- BS.concat <$> gatherAll
+  when (BS.length stream < 5) $
+    throwString ("lz4 decompress error: not enough bytes for header; expected 5, got " ++ show (BS.length stream))
+  frames stream
+  where
+    gatherAll = await >>= \case
+      Nothing -> return []
+      Just bs -> (bs :) <$> gatherAll
+
+    le32 :: ByteString -> Int -> Word32
+    le32 b i = fromIntegral (BS.index b i) .|. (fromIntegral (BS.index b (i + 1)) `shiftL` 8)
+           .|. (fromIntegral (BS.index b (i + 2)) `shiftL` 16) .|. (fromIntegral (BS.index b (i + 3)) `shiftL` 24)
+
+    frames :: ByteString -> ConduitT ByteString ByteString m ()
+    frames rest
+      | BS.null rest = return ()
+      | BS.length rest < 4 = throwString "lz4frame error: \"ERROR_frameHeader_incomplete\""
+      | le32 rest 0 .&. 0xFFFFFFF0 == 0x184D2A50 = do                       -- skippable frame: magic, u32 size, payload
+          when (BS.length rest < 8) $ throwString "lz4frame error: \"ERROR_frameHeader_incomplete\""
+          let sz = fromIntegral (le32 rest 4) :: Int
+          when (BS.length rest - 8 < sz) $ throwString "lz4 decompress error: stream ended before EndMark"
+          frames (BS.drop (8 + sz) rest)
+      | otherwise = do
+          used <- oneFrame rest
+          frames (BS.drop used rest)
+
+    -- One frame.  The C call runs on its own thread and hands every piece of output over through a one-place MVar, so the
+    -- conduit yields while the next slab is being decoded and nothing piles up.  If the conduit is abandoned downstream, the
+    -- cancel flag makes the callback drop what is left, and the call runs to its end without blocking.
+    oneFrame :: ByteString -> ConduitT ByteString ByteString m Int
+    oneFrame frame = bracketP setup teardown $ \(box, _, finished, _) ->
+      let loop = liftIO (takeMVar box) >>= \case
+            Chunk bs -> yield bs >> loop
+            Done r used -> do
+              liftIO (writeIORef finished True)
+              void (liftIO (checkLz4 (return r)))                           -- same exception text as the reference's
+              when (used == 0) $ throwString "lz4 decompress error: stream ended before EndMark"
+              return (fromIntegral used)
+      in loop
+      where
+        setup = do
+          box <- newEmptyMVar :: IO (MVar Handoff)
+          cancelled <- newIORef False
+          finished <- newIORef False
+          cb <- mkYieldFn $ \_ dat n -> do
+            gone <- readIORef cancelled
+            unless gone $ putMVar box . Chunk =<< packCStringLen (dat, fromIntegral n)
+          _ <- forkIO $ unsafeUseAsCStringLen frame $ \(p, n) -> alloca $ \usedPtr -> do
+            r <- c_decompressFrameTo cb nullPtr p (fromIntegral n) usedPtr
+            used <- peek usedPtr
+            putMVar box (Done r used)
+          return (box, cancelled, finished, cb)
+        teardown (box, cancelled, finished, cb) = do
+          writeIORef cancelled True
+          -- abandoned before the end: take what the callback is still handing over until the call says it is done;
+          -- only then may the callback be freed
+          let drain = takeMVar box >>= \case
+                Done _ _ -> return ()
+                Chunk _  -> drain
+          seen <- readIORef finished
+          unless seen drain
+          freeHaskellFunPtr cb

@@ -230,9 +230,9 @@ LZ4F_MI355X_API size_t lz4f_mi355x_dev_workspace_size(size_t srcSize, const LZ4F
  * stream.  d_result (device, optional) receives size/status; d_table (device, optional,
  * >= srcSize/blockSize+1 entries) receives the block table, which dev_decompressBlocks accepts
  * back to skip the serial walk over the size words.
- * Content checksum (serial over the whole stream by construction) is NOT computed on the device
- * path: prefs with contentChecksumFlag set are rejected with ERROR_contentChecksumFlag_invalid;
- * use the host-pointer calls for such frames.                                             */
+ * Content checksum (prefs->frameInfo.contentChecksumFlag): XXH32 over the whole input is one
+ * dependent chain, so ONE workgroup computes it (k_xxh32_content: the four accumulators on four
+ * waves) at a few GB/s - far below the codec; the word lands behind the EndMark as liblz4's does.  */
 LZ4F_MI355X_API size_t lz4f_mi355x_dev_compressFrame(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity,
                                                      const void* d_src, size_t srcSize, const LZ4F_preferences_t* prefs,
                                                      lz4f_mi355x_result* d_result, lz4f_mi355x_block* d_table);
@@ -240,7 +240,10 @@ LZ4F_MI355X_API size_t lz4f_mi355x_dev_compressFrame(lz4f_mi355x_engine* e, void
 /* First frame at d_frame[0..frameCapacity) -> d_dst.  Peeks the 7..19 header bytes (one small
  * device->host copy), then everything is asynchronous: a walk kernel chases the size words, block
  * checksums are verified on the GPU, blocks are decoded.  A content checksum present in the
- * frame is skipped, not verified (see above).                                                 */
+ * frame is verified behind the decode (same single workgroup as above; a mismatch gives
+ * ERROR_contentChecksum_invalid in result.status); an engine made with
+ * LZ4F_MI355X_NO_CONTENT_CHECK set in the environment skips that, as liblz4 >= 1.9.4 can
+ * (LZ4F_decompressOptions_t.skipChecksums).                                                   */
 LZ4F_MI355X_API size_t lz4f_mi355x_dev_decompressFrame(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity,
                                                        const void* d_frame, size_t frameCapacity,
                                                        lz4f_mi355x_result* d_result);
@@ -270,6 +273,20 @@ LZ4F_MI355X_API size_t lz4f_mi355x_dev_index_size(size_t srcSize, const LZ4F_pre
  * same bytes; lz4f_mi355x_dev_decompressFrame finds the trailer from the stream's last 16 bytes and, after checking it against
  * the frame itself, skips the walk over the size words and parses with the index. */
 #define LZ4F_MI355X_INBAND ((size_t)-1)
+/* result.flags: bits 0..7 the frame's FLG byte, bit 8 a skippable frame was skipped; bits 12.. say which way a decompress call
+ * went - a pure function of the call's arguments, the frame's header and trailer and the switches the engine was made with,
+ * never of earlier calls (tests/test_gpu_parity.py: test_decode_path_by_input_class) */
+#define LZ4F_MI355X_PATH_TABLE_GIVEN   0x001u   /* the caller's block table: no walk */
+#define LZ4F_MI355X_PATH_TRAILER       0x002u   /* the size words' positions came from the frame's trailer (checked link by link) */
+#define LZ4F_MI355X_PATH_PARALLEL_WALK 0x004u   /* the size words were looked for in parallel (small blocks) */
+#define LZ4F_MI355X_PATH_INDEXED       0x008u   /* sequence index: parse per entry, direct matches, copier workgroups */
+#define LZ4F_MI355X_PATH_SELF_INDEX    0x010u   /* linked frame without an index: the decoder made one */
+#define LZ4F_MI355X_PATH_DOUBLING      0x020u   /* dense frame: pointer doubling was set up (the device decides whether it runs) */
+#define LZ4F_MI355X_PATH_TRACE_HOPS    0x040u   /* dense frame: the hop-by-hop tracer was set up */
+#define LZ4F_MI355X_PATH_WINDOW        0x080u   /* linked frame: the single-workgroup window kernel was launched (it returns at once behind a successful indexed decode) */
+#define LZ4F_MI355X_PATH_FUSED         0x100u   /* fused parse+copy workgroups were launched (alone, or as what the others fall back to) */
+#define LZ4F_MI355X_PATH_WAVE_PER_BLOCK 0x200u  /* small independent blocks: a wave per block */
+#define LZ4F_MI355X_PATH_INDEX_DROPPED 0x400u   /* set on the device: the indexed kernels refused the index, the generic ones decoded */
 LZ4F_MI355X_API size_t lz4f_mi355x_trailer_bound(size_t srcSize, const LZ4F_preferences_t* prefs);
 LZ4F_MI355X_API size_t lz4f_mi355x_dev_compressFrameIndexed(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize,
                                                             const LZ4F_preferences_t* prefs, lz4f_mi355x_result* d_result,

@@ -39,6 +39,10 @@ struct ResultRec {           // mirrors lz4f_mi355x_result
     uint32_t status, n_blocks, first_bad_block, flags;
 };
 
+// sequence descriptor the decoders hand from their parse to their copies: x = lit_src | off[7:0] << 24, y = lit_len | off[15:8] << 24,
+// z = dst, w = match_len (0: last sequence).  Positions and lengths are < 2^23 because a block holds at most 4 MiB.
+struct SeqDesc { uint32_t x, y, z, w; };
+
 // ---- XXH32 constants ----
 constexpr uint32_t XP1 = 2654435761u, XP2 = 2246822519u, XP3 = 3266489917u, XP4 = 668265263u, XP5 = 374761393u;
 __device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }

@@ -2,7 +2,7 @@
 // parse and copy overlapped.
 //
 // The sequence parse of a block is one serial dependent chain (~0.6 us per sequence on one wave); the copies are
-// where the bytes are.  Running them back to back (decode_2k.cuh) costs parse + copy; here they overlap, so a block
+// where the bytes are.  Running them back to back (a parse kernel, then a copy kernel) costs parse + copy; here they overlap, so a block
 // costs max(parse, copy) ~ parse:
 //   wave 0        PARSER.  Wave-uniform (SALU) state machine.  The payload streams through two 8 KiB LDS stages
 //                 filled by direct-to-LDS loads (global_load_lds_dwordx4) one stage ahead, one 8-byte LDS read per
@@ -19,7 +19,6 @@
 #pragma once
 #include "common.cuh"
 #include "decode.cuh"
-#include "decode_2k.cuh"
 
 namespace lz4f {
 
@@ -39,10 +38,11 @@ constexpr uint32_t FZ_OVER = 576;                // >= the parser's 520-byte reg
 constexpr int      FZ_MATCH_SET = 3;
 constexpr uint32_t FZ_SRC_BIAS = 1u << 22;       // direct matches: payload position relative to the block's payload + this (== IX_SRC_BIAS)
 constexpr uint32_t FZ_PEND = 32;                // linked, fed: matches set aside until the block in front is done
-constexpr uint64_t FZ_PREV_WAIT_TICKS = 300ull * 100000000ull;  // 300 s of the 100 MHz clock: how long a workgroup waits for the one in front before
-                                                                // it gives up (-> generic decoder).  A safety net (they are dispatched in order) that has
-                                                                // to outlast a whole dense frame whose groups run one after the other.
-__device__ __forceinline__ bool fz_wait_expired(uint64_t t0) { return __builtin_amdgcn_s_memrealtime() - t0 > FZ_PREV_WAIT_TICKS; }            // match copies per register set (two sets in flight)
+// How long a workgroup of a linked frame waits for the one in front before it gives up (-> generic decoder): a safety net (they
+// are dispatched in order) that has to outlast a whole dense frame whose groups run one after the other.  The host derives it from
+// the frame's output size (engine.hip: fz_wait_budget - half a second plus 20 ticks of the 100 MHz clock per byte, a fifth of the
+// slowest chain measured) and hands it to the kernel, which keeps it in LDS (FzShared::wait_lo/hi).
+__device__ __forceinline__ bool fz_wait_expired(uint64_t t0, uint64_t budget) { return __builtin_amdgcn_s_memrealtime() - t0 > budget; }
 
 template <class C>
 struct alignas(16) FzShared {
@@ -57,11 +57,12 @@ struct alignas(16) FzShared {
     uint32_t slot_done[C::RING];                // [slot % RING] == slot + 1: that slot's copies are all in memory
     uint32_t slot_cnt[C::RING];                 // fed descriptors: how many of them the slot holds (small blocks are cut into shorter slots)
     uint32_t pend_n, prev_ready, own_front;     // own_front: bytes of output in front of this block that are this workgroup's own (a group of linked blocks)
-    uint32_t pad_pend;   //               // linked frames through the index: matches waiting for the block in front (see fz_copier)
+    uint32_t wait_lo;                           // (with wait_hi) the budget of a wait for the workgroup in front, in ticks of the 100 MHz clock
+    // linked frames through the index: matches waiting for the block in front (see fz_copier)
     uint32_t pend_dst[FZ_PEND], pend_len[FZ_PEND], pend_off[FZ_PEND];
     int32_t  status;                            // < 0: malformed block
     uint32_t out_size;
-    uint32_t pad;
+    uint32_t wait_hi;
 };
 static_assert(sizeof(FzShared<FzCfg<8>>) <= FzCfg<8>::LDS_BUDGET && sizeof(FzShared<FzCfg<4>>) <= FzCfg<4>::LDS_BUDGET, "workgroups per CU");
 
@@ -509,9 +510,10 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
                         // no room on the list: wait for the block in front after all (workgroups are dispatched in block order, so it
                         // is running or finished; the poll has a budget), replay what is on the list, go on without one
                         uint32_t v = 0;                                       // (1 = all of it done, 2 = failed; 3 = only its main pass: not enough here)
+                        const uint64_t budget = (uint64_t)lds_peek(&sh.wait_lo) | ((uint64_t)lds_peek(&sh.wait_hi) << 32);
                         for (const uint64_t t0 = __builtin_amdgcn_s_memrealtime();;) {
                             v = __hip_atomic_load(prev_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (v == 1u || v == 2u || fz_wait_expired(t0)) break;
+                            if (v == 1u || v == 2u || fz_wait_expired(t0, budget)) break;
                             __builtin_amdgcn_s_sleep(8);
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

@@ -30,7 +30,6 @@
 #pragma once
 #include "common.cuh"
 #include "decode.cuh"
-#include "decode_2k.cuh"
 #include "decode_fused.cuh"
 #include "decode_linked.cuh"
 #include "encode.cuh"
@@ -56,15 +55,19 @@ __device__ __forceinline__ void pt_load16(const uint8_t* __restrict__ in, uint32
 // The index header is checked on the device (no host round trip on this path): usable at all, made for this geometry, its
 // tables inside the buffer the caller named, its sequences inside the descriptor workspace the engine has.  flags[0] != 0
 // sends the call to the generic decoder; flags[8] / flags[9] carry the entry and sequence counts to the kernels behind.
-__global__ void k_check_index(const void* __restrict__ ix, uint64_t ix_size, uint32_t n_blocks, uint32_t chunks_per_block, uint32_t chunk_size,
+__global__ void k_check_index(const void* __restrict__ ix, uint64_t ix_size, uint32_t n_max, uint32_t chunks_per_block, uint32_t chunk_size,
                               uint64_t seq_cap, uint32_t* __restrict__ flags, const ResultRec* __restrict__ res = nullptr)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // the index is laid out for the frame's block count: the walk's (res), of which the host knows an upper bound (its own
+    // index for a linked frame) or a claim (the trailer's: a frame with more blocks than that is not this index's frame)
+    const uint32_t n_blocks = res ? res->n_blocks : n_max;
     const IxHeader hd = *(const IxHeader*)ix;
-    const bool ok = (!res || (res->status == ST_OK && res->n_blocks == n_blocks)) && hd.magic == IX_MAGIC && hd.n_blocks == n_blocks && hd.chunks_per_block == chunks_per_block && hd.stride == IX_STRIDE &&
+    const bool ok = (!res || res->status == ST_OK) && n_blocks != 0 && n_blocks <= n_max && hd.magic == IX_MAGIC && hd.n_blocks == n_blocks && hd.chunks_per_block == chunks_per_block && hd.stride == IX_STRIDE &&
                     hd.total_entries <= (uint64_t)n_blocks * chunks_per_block * ix_max_entries_per_chunk(chunk_size) &&
                     hd.total_seqs <= (uint64_t)hd.total_entries * (IX_STRIDE + 1) && hd.total_seqs <= seq_cap &&
                     ix_entries_at(n_blocks, chunks_per_block) + (uint64_t)hd.total_entries * sizeof(IxEntry) <= ix_size;
+    flags[7] = n_blocks;
     flags[8] = ok ? hd.total_entries : 0u;
     flags[9] = ok ? hd.total_seqs : 0u;
     if (!ok) atomicOr(flags, 1u);
@@ -183,10 +186,11 @@ __device__ __forceinline__ void parse_entry(const uint8_t* __restrict__ frame, u
 }
 
 __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
-                                                       const void* __restrict__ ix, uint32_t n_blocks,
+                                                       const void* __restrict__ ix, uint32_t n_max,
                                                        SeqDesc* __restrict__ desc, uint32_t* __restrict__ flags, uint32_t linked, uint64_t hist0)
 {
     if (*flags) return;
+    const uint32_t n_blocks = flags[7] < n_max ? flags[7] : n_max;      // (k_check_index: the frame's block count)
     const uint32_t n_entries = flags[8];
     const uint64_t desc_cap = flags[9];
     const uint32_t n_lanes = n_entries > n_blocks ? n_entries : n_blocks;
@@ -787,7 +791,8 @@ template <class C>
 __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(const uint8_t* __restrict__ frame, uint8_t* dst, BlockOut* __restrict__ table,
                                                                    const ResultRec* __restrict__ res, uint32_t n_max, void* __restrict__ ix,
                                                                    const SeqDesc* __restrict__ desc, const uint32_t* __restrict__ dsrc, uint32_t* __restrict__ flags,
-                                                                   unsigned long long* prof, uint32_t linked, uint32_t* __restrict__ done, uint32_t group, uint64_t hist0)
+                                                                   unsigned long long* prof, uint32_t linked, uint32_t* __restrict__ done, uint32_t group, uint64_t hist0,
+                                                                   uint64_t wait_ticks)
 {   // group: consecutive blocks per workgroup (1 except for small blocks of a linked frame, see below)
     __shared__ FzShared<C> sh;
     if (res->status != ST_OK || *flags || flags[IXT_FLAG]) return;           // index unusable: the generic kernel launched behind does the work; dense: traced
@@ -837,6 +842,7 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(cons
     bool failed = false;
     uint32_t last_size = 0, own_front = 0;
     BlockOut e{};
+    if (tid == 0) { sh.wait_lo = (uint32_t)wait_ticks; sh.wait_hi = (uint32_t)(wait_ticks >> 32); }      // (read by fz_copier, behind fz_decode_block's barrier)
     for (uint32_t b = b0; b < b1 && !failed; b++) {
         e = table[b];
         const uint32_t csz = e.word & 0x7FFFFFFFu;
@@ -881,7 +887,7 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(cons
             uint32_t v = 0;
             auto poll = [&](bool all) {
                 // (relaxed polls, one acquire at the end: an acquire per poll would empty this CU's vector cache every time)
-                for (const uint64_t t0 = __builtin_amdgcn_s_memrealtime(); !fz_wait_expired(t0);) {
+                for (const uint64_t t0 = __builtin_amdgcn_s_memrealtime(); !fz_wait_expired(t0, wait_ticks);) {
                     v = __hip_atomic_load(pd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (v == 1u || v == 2u || (v == 3u && !all)) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); return; }
                     __builtin_amdgcn_s_sleep(8);

@@ -22,7 +22,6 @@
 #pragma once
 #include "common.cuh"
 #include "decode.cuh"
-#include "decode_2k.cuh"
 #include "decode_fused.cuh"
 
 namespace lz4f {

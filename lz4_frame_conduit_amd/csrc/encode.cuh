@@ -38,7 +38,7 @@ struct ChunkInfo {           // 32 bytes, one per chunk
 struct EncGeom {
     uint64_t src_size;           // bytes readable at src (history + blocks)
     uint64_t first_off;          // block 0 starts here; bytes in front of it are history (used when linked)
-    uint32_t write_endmark;      // 0: emit blocks only (streaming API), 1: header + blocks + EndMark
+    uint32_t write_endmark;      // 0: emit blocks only (streaming API), 1: header + blocks + EndMark, 2: + room for the content checksum
     uint32_t block_size;
     uint32_t chunk_size;         // divides block_size
     uint32_t chunks_per_block;
@@ -647,7 +647,7 @@ __global__ __launch_bounds__(1024) void k_layout_scan(EncGeom g, BlockOut* __res
         if (t == 1023) s_carry += s_part[1023];
         __syncthreads();
     }
-    const uint64_t frame_size = s_carry + (g.write_endmark ? 4 : 0);
+    const uint64_t frame_size = s_carry + (g.write_endmark == 2 ? 8 : g.write_endmark ? 4 : 0);
     const bool fits = frame_size <= dst_cap;
     if (fits) {
         if (t < g.header_size) dst[t] = g.header[t];

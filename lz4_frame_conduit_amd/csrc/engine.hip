@@ -78,6 +78,22 @@ uint32_t pick_chunk_size(uint32_t block_size)
     return block_size < c ? block_size : c;
 }
 
+}  // namespace lz4f
+void lz4f_mi355x_engine::Switches::read()
+{
+    auto on = [](const char* n) { return getenv(n) != nullptr; };
+    no_index = on("LZ4F_MI355X_NO_INDEX"); no_selfindex = on("LZ4F_MI355X_NO_SELFINDEX"); no_resolve = on("LZ4F_MI355X_NO_RESOLVE");
+    no_trace = on("LZ4F_MI355X_NO_TRACE"); no_doubling = on("LZ4F_MI355X_NO_DOUBLING"); trace_always = on("LZ4F_MI355X_TRACE_ALWAYS");
+    no_groups = on("LZ4F_MI355X_NO_GROUPS"); no_window = on("LZ4F_MI355X_NO_WINDOW"); serial_walk = on("LZ4F_MI355X_SERIAL_WALK");
+    no_trailer = on("LZ4F_MI355X_NO_TRAILER"); no_content_check = on("LZ4F_MI355X_NO_CONTENT_CHECK"); prof = on("LZ4F_MI355X_PROF"); e1_sync = on("LZ4F_MI355X_E1_SYNC");
+    chain_gate = 0; if (const char* v = getenv("LZ4F_MI355X_CHAIN_GATE")) { const int g = atoi(v); if (g > 0 && g < (1 << 20)) chain_gate = g; }
+    decode_mode = 0; if (const char* v = getenv("LZ4F_MI355X_DECODE")) decode_mode = v[0];
+    e1_run = 0; if (const char* v = getenv("LZ4F_MI355X_E1_RUN")) { const int g = atoi(v); if (g >= 1 && g <= 4096) e1_run = (unsigned)g; }
+    e1_solo = 0; if (const char* v = getenv("LZ4F_MI355X_E1_SOLO")) e1_solo = (unsigned)atoi(v);
+    wait_ticks = 0; if (const char* v = getenv("LZ4F_MI355X_WAIT_TICKS")) { unsigned long long a = 0; if (sscanf(v, "%llu", &a) == 1) wait_ticks = a; }
+    seed = 2; if (const char* v = getenv("LZ4F_MI355X_SEED")) { unsigned a = 0; if (sscanf(v, "%u", &a) == 1 && a >= 1 && a <= 64) seed = a; }
+}
+namespace lz4f {
 size_t new_engine(lz4f_mi355x_engine** out, int device, void* stream, bool borrow)
 {
     int n = 0;
@@ -90,6 +106,7 @@ size_t new_engine(lz4f_mi355x_engine** out, int device, void* stream, bool borro
     HIP_TRY(hipSetDevice(device));
     lz4f_mi355x_engine* en = new lz4f_mi355x_engine();
     en->device = device;
+    en->sw.read();
     if (borrow) { en->stream = stream; en->own_stream = false; }
     else {
         hipStream_t s;
@@ -151,8 +168,6 @@ lz4f_mi355x_engine::~lz4f_mi355x_engine()
     d_in.release(); d_out.release();
     h_in.release(); h_out.release(); h_small.release();
     for (int i = 0; i < 20; i++) if (ev[i]) (void)hipEventDestroy((hipEvent_t)ev[i]);
-    if (ix_ev) (void)hipEventDestroy((hipEvent_t)ix_ev);
-    h_ix.release();
     if (own_stream && stream) (void)hipStreamDestroy((hipStream_t)stream);
 }
 
@@ -205,7 +220,7 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     hipStream_t st = (hipStream_t)stream;
     EncGeom g;
     memset(&g, 0, sizeof(g));
-    g.src_size = j.src_size; g.first_off = j.first_off; g.write_endmark = j.endmark ? 1 : 0;
+    g.src_size = j.src_size; g.first_off = j.first_off; g.write_endmark = j.endmark ? (j.content_checksum ? 2 : 1) : 0;
     g.block_size = j.block_size;
     g.chunk_size = pick_chunk_size(j.block_size);
     g.chunks_per_block = j.block_size / g.chunk_size;
@@ -216,8 +231,7 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     g.linked = j.linked; g.block_checksum = j.block_checksum;
     g.header_size = j.header_size; memcpy(g.header, j.header, j.header_size);
     g.max_rec_per_chunk = g.chunk_size / 4 + 1;
-    g.seed_stride = 2;
-    if (const char* sv = getenv("LZ4F_MI355X_SEED")) { unsigned a = 0; if (sscanf(sv, "%u", &a) == 1 && a >= 1 && a <= 64) g.seed_stride = a; }
+    g.seed_stride = sw.seed;
 
     if (info.ensure((size_t)(g.n_chunks + 1) * sizeof(ChunkInfo))) return make_err(LZ4F_ERROR_allocation_failed);
     if (recs.ensure((size_t)(g.n_chunks + 1) * g.max_rec_per_chunk * 8)) return make_err(LZ4F_ERROR_allocation_failed);
@@ -235,16 +249,16 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
             // has its slice lists in `e1_scratch`), runs of at least 16 tiles where the input is big enough for 1024 of those
             // (the history loaded in front of a run is then 1/16 of the input or less)
             uint32_t run = (g.n_chunks + 1023) / 1024; if (run < 16) { run = g.n_chunks / 1024; run = run < 1 ? 1 : run > 16 ? 16 : run; }
-            if (const char* rv = getenv("LZ4F_MI355X_E1_RUN")) { const int v = atoi(rv); if (v >= 1 && v <= 4096) run = (uint32_t)v; }
+            if (sw.e1_run) run = sw.e1_run;
             g.tiles_per_wg = run;
-            g.e1_solo = getenv("LZ4F_MI355X_E1_SOLO") ? (uint32_t)atoi(getenv("LZ4F_MI355X_E1_SOLO")) : 0u;
+            g.e1_solo = sw.e1_solo;
             const uint32_t n_wg = (g.n_chunks + run - 1) / run;
             if (e1_scratch.ensure((size_t)n_wg * 2 * E1_NSLICE * E1_REC_PER_SLICE * 8 + 2048)) return make_err(LZ4F_ERROR_allocation_failed);
 #ifdef E1_DEBUG
             (void)hipMemsetAsync((uint8_t*)e1_scratch.p + (size_t)n_wg * 2 * E1_NSLICE * E1_REC_PER_SLICE * 8, 0, 2048, st);
 #endif
             hipLaunchKernelGGL(k_find_matches, dim3(n_wg), dim3(64 * E1_WAVES), 0, st, j.d_src, g, (ChunkInfo*)info.p, (uint64_t*)recs.p, (uint64_t*)e1_scratch.p);
-            if (getenv("LZ4F_MI355X_E1_SYNC")) (void)hipStreamSynchronize(st);
+            if (sw.e1_sync) (void)hipStreamSynchronize(st);
 #ifdef E1_DEBUG
             { unsigned long long d[256]; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(d, (uint8_t*)e1_scratch.p + (size_t)n_wg * 2 * E1_NSLICE * E1_REC_PER_SLICE * 8, 2048, hipMemcpyDeviceToHost) == hipSuccess) {
                 for (int w = 0; w < 16; w += 5) { unsigned long long* x = d + 16 + w * 8; if (x[6]) fprintf(stderr, "E1 wave %d: per tile cycles: merge %llu parse %llu waitB1 %llu dma-issue %llu dma-wait %llu waitB2 %llu (%llu tiles)\n", w, x[0]/x[6], x[1]/x[6], x[2]/x[6], x[3]/x[6], x[4]/x[6], x[5]/x[6], x[6]); unsigned long long* f = d + 160 + w * 6; fprintf(stderr, "   parse: dequeue %llu cycles x %llu, probe step %llu cycles x %llu, hit %llu cycles x %llu (per tile)\n", f[3] ? f[0]/f[3] : 0, f[3]/x[6], f[4] ? f[1]/f[4] : 0, f[4]/x[6], f[5] ? f[2]/f[5] : 0, f[5]/x[6]); }
@@ -271,11 +285,16 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
         tick(2, true);
         if (j.block_checksum) {
             tick(3, false);
+            if (g.n_blocks < XXH_WG_BELOW)                             // few big blocks: four waves each (wg4_xxh32)
+                hipLaunchKernelGGL(k_xxh32_blocks4, dim3(g.n_blocks), dim3(256), 0, st, d_dst, (BlockOut*)d_table, (const ResultRec*)d_res, g.n_blocks, 0u, (uint32_t*)nullptr);
+            else
             hipLaunchKernelGGL((k_xxh32_blocks<W>), dim3((g.n_blocks + W - 1) / W), dim3(64 * W), 0, st, d_dst, (BlockOut*)d_table,
                                (const ResultRec*)d_res, g.n_blocks, 0u, (uint32_t*)nullptr);
             tick(3, true);
         }
     }
+    if (j.endmark && j.content_checksum)                              // (one chain over the whole input: see k_xxh32_content for what that costs)
+        hipLaunchKernelGGL(k_xxh32_content, dim3(1), dim3(256), 0, st, j.d_src + j.first_off, (uint64_t)(j.src_size - j.first_off), d_dst, (ResultRec*)d_res, 0u);
     if (inband && g.n_blocks) {
         TrailerPlan* plan = (TrailerPlan*)((uint8_t*)res.p + sizeof(ResultRec) + 32);
         hipLaunchKernelGGL(k_trailer_plan, dim3(1), dim3(64), 0, st, d_dst, dst_cap, (ResultRec*)d_res, g.n_blocks, (const void*)d_index,
@@ -294,6 +313,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
     if (bad.ensure(64)) return make_err(LZ4F_ERROR_allocation_failed);
     BlockOut* tbl;
     uint32_t n_max;
+    uint32_t plan = 0;                                               // LZ4F_MI355X_PATH_*: reported in result.flags
     for (int i = 4; i < 10; i++) ev_used[i] = false;
     if (j.d_table || j.table_in_place) {
         // caller-supplied table: work on a copy (decode overwrites dst_size)
@@ -303,6 +323,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         if (!j.table_in_place)
             HIP_TRY(hipMemcpyAsync(tbl, j.d_table, (size_t)n_max * sizeof(BlockOut), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_init_result, dim3(1), dim3(64), 0, st, (ResultRec*)d_res, n_max, 0u);
+        plan |= LZ4F_MI355X_PATH_TABLE_GIVEN;
     } else {
         n_max = j.max_blocks;
         if (table.ensure((size_t)(n_max + 1) * sizeof(BlockOut))) return make_err(LZ4F_ERROR_allocation_failed);
@@ -320,8 +341,9 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             hipLaunchKernelGGL(k_walk_link, dim3(std::min<uint32_t>((j.hint_n + 255) / 256, 4096u)), dim3(256), 0, st, j.d_frame, j.frame_cap, j.dst_cap, ws, j.hint_list, tbl, n_max);
             hipLaunchKernelGGL(k_walk_verdict, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, j.dst_cap, ws, j.hint_list, n_max, (ResultRec*)d_res);
             walked = &ws->done;
+            plan |= LZ4F_MI355X_PATH_TRAILER;
         } else
-        if (j.block_size <= (256u << 10) && j.frame_cap >= (1u << 20) && !getenv("LZ4F_MI355X_SERIAL_WALK")) {
+        if (j.block_size <= (256u << 10) && j.frame_cap >= (1u << 20) && !sw.serial_walk) {
             const uint32_t n_chunks = (uint32_t)((j.frame_cap + WK_CHUNK - 1) / WK_CHUNK);
             const size_t list_cap = (size_t)n_max + 1024;
             const size_t at_chunks = 256, at_list = at_chunks + (size_t)n_chunks * sizeof(WalkChunk), at_list2 = at_list + list_cap * 8, at_mark = at_list2 + list_cap * 8;
@@ -341,7 +363,8 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             hipLaunchKernelGGL(k_walk_link, dim3(lgrid), dim3(256), 0, st, j.d_frame, j.frame_cap, j.dst_cap, ws, (const uint64_t*)list2, tbl, n_max);
             hipLaunchKernelGGL(k_walk_verdict, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, j.dst_cap, ws, (const uint64_t*)list2, n_max, (ResultRec*)d_res);
             walked = &ws->done;
-            if (getenv("LZ4F_MI355X_PROF")) { WalkState h; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(&h, ws, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "parallel walk: done %u overflow %u candidates %u first_end %u first_break %u (header ok %u, hsize %u, block %u)\n", h.done, h.overflow, h.total, h.first_end, h.first_break, h.head_ok, h.hsize, h.bs); }
+            plan |= LZ4F_MI355X_PATH_PARALLEL_WALK;
+            if (sw.prof) { WalkState h; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(&h, ws, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "parallel walk: done %u overflow %u candidates %u first_end %u first_break %u (header ok %u, hsize %u, block %u)\n", h.done, h.overflow, h.total, h.first_end, h.first_break, h.head_ok, h.hsize, h.bs); }
         }
         hipLaunchKernelGGL(k_walk_frame, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, j.dst_cap, tbl, n_max, (ResultRec*)d_res, walked);
         tick(4, true);
@@ -349,34 +372,37 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
     HIP_TRY(hipMemsetAsync(bad.p, 0xFF, 4, st));
     constexpr int W = 4;
     const uint32_t grid = j.linked ? 1u : (n_max + W - 1) / W;
+    const uint32_t* ix_flags = nullptr;                              // the indexed kernels' "gave up" word, if they were launched
     if (n_max) {
         if (j.block_checksum) {
             tick(5, false);
+            if (n_max < XXH_WG_BELOW)
+                hipLaunchKernelGGL(k_xxh32_blocks4, dim3(n_max), dim3(256), 0, st, (uint8_t*)j.d_frame, tbl, (const ResultRec*)d_res, n_max, 1u, (uint32_t*)bad.p);
+            else
             hipLaunchKernelGGL((k_xxh32_blocks<W>), dim3((n_max + W - 1) / W), dim3(64 * W), 0, st, (uint8_t*)j.d_frame, tbl,
                                (const ResultRec*)d_res, n_max, 1u, (uint32_t*)bad.p);
             tick(5, true);
         }
         tick(6, false);
-        // one workgroup (8 waves) per block when blocks are few and large, one wave per block otherwise
-        // large blocks / linked frames: fused parse+copy workgroups ('f', default), or the two-kernel variant ('2');
-        // small independent blocks: one wave per block ('1')
+        // large blocks / linked frames: fused parse+copy workgroups ('f'); small independent blocks: one wave per block ('1')
         char mode = (j.linked || j.block_size >= (256u << 10)) ? 'f' : '1';
-        if (const char* dv = getenv("LZ4F_MI355X_DECODE")) mode = dv[0];
+        if (sw.decode_mode) mode = sw.decode_mode;
         bool indexed = false;
         void* d_index = j.d_index; size_t index_size = j.index_size;
         bool self_indexed = false;
+        uint32_t self_seqs = 0, self_entries = 0;
         // A linked frame is one match chain without a usable index (seconds instead of milliseconds on dense data), so for
         // those the header of the index that came along is read NOW (a host synchronisation, ~30 us): the compressor marks an
         // index unusable when the stream had more sequences than it had room for, and then one is made here instead.
         IxHeader hd_now; memset(&hd_now, 0, sizeof(hd_now));
         bool have_now = false;
-        if (mode == 'f' && j.linked && j.d_index && j.index_size >= sizeof(IxHeader) && !getenv("LZ4F_MI355X_NO_INDEX")) {
+        if (mode == 'f' && j.linked && j.d_index && j.index_size >= sizeof(IxHeader) && !sw.no_index) {
             HIP_TRY(hipMemcpyAsync(&hd_now, j.d_index, sizeof(hd_now), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             have_now = true;
             if (hd_now.magic != IX_MAGIC || hd_now.stride != IX_STRIDE) { d_index = nullptr; index_size = 0; have_now = false; }
         }
-        if (mode == 'f' && j.linked && !d_index && j.hist0 <= 65536 && n_max >= 2 && !getenv("LZ4F_MI355X_NO_INDEX") && !getenv("LZ4F_MI355X_NO_SELFINDEX")) {
+        if (mode == 'f' && j.linked && !d_index && j.hist0 <= 65536 && n_max >= 2 && !sw.no_index && !sw.no_selfindex) {
             // A linked frame without an index (a foreign one: the reference's default output): make the index here - a lane per block
             // walks the payload (parsing needs no history), a scan places the blocks - and take the same kernels as with the
             // compressor's index.  Two host synchronisations (the totals size the buffers); anything odd leaves the frame to the
@@ -406,52 +432,44 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                                    (const ResultRec*)d_res, n_max, cnt, osz, selfix.p, (uint32_t*)seqcnt.p);
                 d_index = selfix.p; index_size = fixed + (size_t)tot[8] * sizeof(IxEntry);
                 self_indexed = true;
-                if (ix_seq_cap < (size_t)tot[9] + 4096) ix_seq_cap = (size_t)tot[9] + 4096;
-                if (ix_entries_hint < tot[8]) ix_entries_hint = tot[8];
-                ix_dense_hint = (uint64_t)tot[9] * 48 > (uint64_t)n_max * j.block_size;      // (this very frame's density: see the doubling scratch below)
+                plan |= LZ4F_MI355X_PATH_SELF_INDEX;
+                self_seqs = tot[9]; self_entries = tot[8];
             }
         }
         // (linked frames: only with a table that has every block's output position - the compressor's, or the one just made)
         if (mode == 'f' && d_index && index_size >= sizeof(IxHeader) && (!j.linked || self_indexed || ((j.d_table || j.table_in_place) && j.hist0 <= 65536)) &&
-            !getenv("LZ4F_MI355X_NO_INDEX")) {
+            !sw.no_index) {
             // Descriptors from the compressor's sequence index: a lane per entry parses, a lane per sequence resolves direct
-            // matches, a workgroup per block copies.  The descriptor workspace is sized from the index header.  The first
-            // call reads it back (a host synchronisation); every call leaves a copy of its header in pinned memory behind the
-            // kernels, and the next one sizes from that - the device checks that the workspace is big enough for the index it
-            // actually gets (k_check_index) and otherwise hands the call to the generic decoder.
+            // matches, a workgroup per block copies.
             const uint32_t chunk = pick_chunk_size(j.block_size), cpb = j.block_size / chunk;
             // (an index out of the frame's trailer is laid out for the block count the trailer names; the table and the generic
             // kernels keep the caller's upper bound - if the walk finds another count, the index is dropped on the device)
             const uint32_t n_ix = (j.hint_list && j.hint_n <= n_max) ? j.hint_n : n_max;
-            if (h_ix.ensure(64)) return make_err(LZ4F_ERROR_allocation_failed);
-            if (!ix_ev) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ix_ev = e; }
-            IxHeader hd; memset(&hd, 0, sizeof(hd));
-            bool have = false;
-            if (ix_pending && hipEventQuery((hipEvent_t)ix_ev) == hipSuccess) {
-                memcpy(&hd, h_ix.p, sizeof(hd)); ix_pending = false; have = true;
-                uint32_t decided = 0; memcpy(&decided, (const uint8_t*)h_ix.p + 32, 4);
-                ix_chain_hint = decided != 0;                              // (the last frame was decoded from its bytes' origins: expect the next one to be)
-            }
-            if (!have && ix_seq_cap == 0) {
+            // How many sequences and entries the index holds comes with THIS call (the trailer's footer, the self-index scan, or one
+            // read of the index header for the explicit-index entry point): it sizes the descriptor workspace and decides whether a
+            // dense frame's scratch is worth having.  Nothing is carried over from earlier calls; the device checks the real header
+            // against the workspace (k_check_index) and hands the call to the generic decoder if it does not fit.
+            uint32_t ix_seqs = j.ix_seqs, ix_entries = j.ix_entries;
+            if (self_indexed) { ix_seqs = self_seqs; ix_entries = self_entries; }
+            else if (have_now) { ix_seqs = hd_now.total_seqs; ix_entries = hd_now.total_entries; }
+            else if (!ix_seqs) {
+                IxHeader hd; memset(&hd, 0, sizeof(hd));
                 HIP_TRY(hipMemcpyAsync(&hd, d_index, sizeof(hd), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
-                have = true;
+                if (hd.magic == IX_MAGIC && hd.stride == IX_STRIDE) { ix_seqs = hd.total_seqs; ix_entries = hd.total_entries; }
             }
-            if (have_now && !self_indexed) { hd = hd_now; have = true; }          // (linked frames: this very index's header, read above)
-            if (have && hd.magic == IX_MAGIC && hd.stride == IX_STRIDE && hd.total_seqs <= (uint64_t)hd.total_entries * (IX_STRIDE + 1) &&
-                hd.total_entries <= (index_size - sizeof(IxHeader)) / sizeof(IxEntry)) {
-                if (hd.total_seqs > ix_seq_cap) ix_seq_cap = (size_t)hd.total_seqs + hd.total_seqs / 4 + 4096;      // (a quarter of slack: the next stream differs)
-                if (hd.total_entries > ix_entries_hint) ix_entries_hint = hd.total_entries + hd.total_entries / 4;
-                ix_dense_hint = (uint64_t)hd.total_seqs * 48 > (uint64_t)hd.n_blocks * j.block_size;      // (short sequences: worth the tracer's scratch, see below)
-            }
-            if (ix_seq_cap) {
+            if ((uint64_t)ix_seqs > (uint64_t)ix_entries * (IX_STRIDE + 1) || ix_entries > (index_size - sizeof(IxHeader)) / sizeof(IxEntry)) ix_seqs = 0;      // (not a count this index can hold)
+            const bool ix_dense = (uint64_t)ix_seqs * 48 > (uint64_t)n_ix * j.block_size;      // short sequences: worth the tracer's scratch, see below
+            const uint32_t ix_entries_hint = ix_entries;
+            if ((size_t)ix_seqs + 4096 > ix_seq_cap) ix_seq_cap = (size_t)ix_seqs + ix_seqs / 4 + 4096;
+            if (ix_seqs) {
                 const size_t dsrc_at = (ix_seq_cap + 64) * sizeof(SeqDesc);
                 if (desc.ensure(dsrc_at + (ix_seq_cap + 64) * 4) || seqcnt.ensure(256 + (size_t)n_max * (8 + 8 * IXL_PUB))) return make_err(LZ4F_ERROR_allocation_failed);
                 HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 256 + (j.linked ? (size_t)n_max * 8 : 0), st));      // flags (+ per block of a linked frame: the "done" word and the count of published ranges)
                 uint32_t* done = (uint32_t*)seqcnt.p + 64;
                 uint32_t lk = j.linked ? 1u : 0u;                                  // (bits 1..: chain gate, see k_copy_indexed)
-                if (j.linked) if (const char* gs = getenv("LZ4F_MI355X_CHAIN_GATE")) { const int gv = atoi(gs); if (gv > 0 && gv < (1 << 20)) lk |= (uint32_t)gv << 1; }
-                unsigned long long* iprof = (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr);
+                if (j.linked && sw.chain_gate) lk |= (uint32_t)sw.chain_gate << 1;
+                unsigned long long* iprof = (unsigned long long*)(sw.prof ? prof_buf() : nullptr);
                 tick(8, false);
                 hipLaunchKernelGGL(k_check_index, dim3(1), dim3(64), 0, st, (const void*)d_index, (uint64_t)index_size, n_ix, cpb, chunk,
                                    (uint64_t)ix_seq_cap, (uint32_t*)seqcnt.p, (const ResultRec*)d_res);
@@ -459,16 +477,16 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 hipLaunchKernelGGL(k_parse_indexed, dim3((n_lanes + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap,
                                    (const BlockOut*)tbl, (const void*)d_index, n_ix, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, lk, (uint64_t)j.hist0);
                 const uint64_t trace_span = (uint64_t)n_ix * j.block_size;            // (the last block may be short)
-                const bool trace_can = !getenv("LZ4F_MI355X_NO_TRACE") && !getenv("LZ4F_MI355X_NO_RESOLVE") && (j.block_size & 63u) == 0;
+                const bool trace_can = !sw.no_trace && !sw.no_resolve && (j.block_size & 63u) == 0;
                 // (pointer doubling does ~12 GiB/s on text whatever the framing; hop by hop it is 1.3 GiB/s, which only pays where
                 // there is no block-level parallelism - linked frames; independent blocks then stay with the copier workgroups, 4.8 GiB/s)
-                const bool can_double = (ix_dense_hint || ix_chain_hint || getenv("LZ4F_MI355X_TRACE_ALWAYS")) && trace_span <= IXP_MAX_SPAN && !getenv("LZ4F_MI355X_NO_DOUBLING");
-                uint32_t gate = !trace_can ? 0u : getenv("LZ4F_MI355X_TRACE_ALWAYS") ? 2u : (j.linked || can_double) ? 1u : 0u;
+                const bool can_double = (ix_dense || sw.trace_always) && trace_span <= IXP_MAX_SPAN && !sw.no_doubling;
+                uint32_t gate = !trace_can ? 0u : sw.trace_always ? 2u : (j.linked || can_double) ? 1u : 0u;
                 if (gate && postab.ensure((size_t)(trace_span >> 6) * 4 + 512 + ((size_t)(trace_span >> IXT_REGION_LOG) + 4) * 4)) gate = 0;      // (no memory for the position table: the copiers do it)
                 if (gate && can_double)                                        // (dense by the sequence density: no need to resolve anything)
                     hipLaunchKernelGGL(k_dense_gate, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, gate, (const BlockOut*)tbl, (const ResultRec*)d_res, n_ix, 1u, 1u);
                 uint32_t* dsrc = (uint32_t*)((uint8_t*)desc.p + dsrc_at);
-                if (getenv("LZ4F_MI355X_NO_RESOLVE")) dsrc = nullptr;
+                if (sw.no_resolve) dsrc = nullptr;
                 else
                     hipLaunchKernelGGL(k_resolve_direct, dim3(n_ix, j.block_size >= (1u << 19) ? j.block_size >> 18 : 1u), dim3(256), 0, st, d_index, (const BlockOut*)tbl, (const ResultRec*)d_res, n_ix, (const SeqDesc*)desc.p,
                                        dsrc, (uint32_t*)seqcnt.p, (iprof ? 1u : 0u) | (gate ? 2u : 0u), lk);
@@ -489,6 +507,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                         // scratch - 4 bytes per output byte - and 18 launches are the host's to spend): one hop per byte, then pointer doubling
                         const bool doubling = can_double && !pdbuf.ensure((size_t)trace_span * 4 + 256 + (IXP_ROUNDS + 1) * IXP_STRIPES * 4);
                         if (doubling) {
+                            plan |= LZ4F_MI355X_PATH_DOUBLING;
                             uint32_t* remaining = (uint32_t*)((uint8_t*)pdbuf.p + (((size_t)trace_span * 4 + 255) & ~(size_t)255));
                             if (hipMemsetAsync(remaining, 0, (IXP_ROUNDS + 1) * IXP_STRIPES * 4, st) != hipSuccess) return make_err(LZ4F_ERROR_GENERIC);
                             hipLaunchKernelGGL(k_pd_init, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, (const BlockOut*)tbl,
@@ -500,6 +519,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                             hipLaunchKernelGGL(k_pd_verdict, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, (const uint32_t*)remaining);
                             if (iprof) { static uint32_t t[(IXP_ROUNDS + 1) * IXP_STRIPES]; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(t, remaining, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) { fprintf(stderr, "doubling: bytes open after each round:"); for (uint32_t r = 0; r <= IXP_ROUNDS; r++) { uint64_t sum = 0; for (uint32_t q = 0; q < IXP_STRIPES; q++) sum += t[r * IXP_STRIPES + q]; fprintf(stderr, " %llu", (unsigned long long)sum); } fprintf(stderr, "\n"); } }
                         } else {
+                        plan |= LZ4F_MI355X_PATH_TRACE_HOPS;
                         uint32_t* region_cnt = (uint32_t*)((uint8_t*)postab.p + (((size_t)(trace_span >> 6) * 4 + 255) & ~(size_t)255));
                         if (hipMemsetAsync(region_cnt, 0, ((size_t)(trace_span >> IXT_REGION_LOG) + 2) * 4, st) != hipSuccess) return make_err(LZ4F_ERROR_GENERIC);
                         hipLaunchKernelGGL(k_trace_copy, dim3((uint32_t)((n_thr + 255) / 256)), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, (const BlockOut*)tbl,
@@ -512,71 +532,64 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 tick(8, true);
                 tick(9, false);
                 // (linked frames of small blocks: a workgroup takes a group of consecutive blocks - see k_copy_indexed)
-                const uint32_t group = (j.linked && j.block_size < (1u << 20) && !getenv("LZ4F_MI355X_NO_GROUPS")) ? (1u << 20) / j.block_size : 1u;
+                const uint32_t group = (j.linked && j.block_size < (1u << 20) && !sw.no_groups) ? (1u << 20) / j.block_size : 1u;
                 const uint32_t n_wg = (n_ix + group - 1) / group;
+                // (how long a group of a linked frame waits for the one in front: half a second plus 20 ticks of the 100 MHz clock per
+                // output byte - 5 MB/s, a fifth of the slowest chain measured (text, linked, 27 MB/s); LZ4F_MI355X_WAIT_TICKS overrides)
+                const uint64_t wait_ticks = sw.wait_ticks ? sw.wait_ticks : 50000000ull + 20ull * n_ix * j.block_size;
                 if (j.block_size <= (1u << 20))
                     hipLaunchKernelGGL(k_copy_indexed<FzCfg<4>>, dim3(n_wg), dim3(64 * 4), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_ix,
-                                       d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done, group, (uint64_t)j.hist0);
+                                       d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done, group, (uint64_t)j.hist0, wait_ticks);
                 else
                     hipLaunchKernelGGL(k_copy_indexed<FzCfg<8>>, dim3(n_wg), dim3(64 * 8), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_ix,
-                                       d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done, group, (uint64_t)j.hist0);
+                                       d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (uint32_t*)seqcnt.p, iprof, lk, done, group, (uint64_t)j.hist0, wait_ticks);
                 tick(9, true);
                 if (iprof && j.linked) { uint32_t y[4] = {0, 0, 0, 0}; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(y, (uint32_t*)seqcnt.p + 20, 16, hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "indexed (linked): blocks that found the block in front at state 3: %u (of those, had to wait for all of it: %u); blocks with set-aside matches %u (block in front already done: %u)\n", y[0], y[1], y[2], y[3]); }
                 indexed = true;
+                ix_flags = (const uint32_t*)seqcnt.p;
+                plan |= LZ4F_MI355X_PATH_INDEXED;
             }
-            // this call's header for the next call (no wait here)
-            HIP_TRY(hipMemcpyAsync(h_ix.p, d_index, sizeof(IxHeader), hipMemcpyDeviceToHost, st));
-            if (indexed) HIP_TRY(hipMemcpyAsync((uint8_t*)h_ix.p + 32, (uint32_t*)seqcnt.p + IXT_DECIDED, 4, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipEventRecord((hipEvent_t)ix_ev, st));
-            ix_pending = true;
         }
         if (mode == 'f') {
-            unsigned long long* prof = (unsigned long long*)(getenv("LZ4F_MI355X_PROF") ? prof_buf() : nullptr);
+            unsigned long long* prof = (unsigned long long*)(sw.prof ? prof_buf() : nullptr);
             // more blocks than the machine has 8-wave workgroup slots: the 4-wave shape keeps twice as many in flight
             const bool small = !j.linked && j.block_size <= (1u << 20);
             // a linked frame is one chain: one workgroup with the 64 KiB window in LDS; frames with short (flushed) blocks
             // set the flag and are decoded by the generic kernel launched right behind (it returns at once otherwise)
-            const bool windowed = j.linked && j.dst_cap < 0xFFF00000ull && !getenv("LZ4F_MI355X_NO_WINDOW");
+            const bool windowed = j.linked && j.dst_cap < 0xFFF00000ull && !sw.no_window;
             const uint32_t* only_if = indexed ? (const uint32_t*)seqcnt.p : nullptr;      // behind the indexed kernels the generic ones only run if they gave up
             if (windowed) {
+                plan |= LZ4F_MI355X_PATH_WINDOW;
                 if (!indexed && seqcnt.ensure(256)) return make_err(LZ4F_ERROR_allocation_failed);
                 uint32_t* fb = (uint32_t*)seqcnt.p + (indexed ? 16 : 0);                  // (word 0 is the indexed kernels' flag)
                 hipLaunchKernelGGL(k_decode_linked, dim3(1), dim3(64 * LK_WAVES), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
                                    (const ResultRec*)d_res, n_max, j.block_size, j.hist0, fb, only_if);
                 only_if = fb;
-                if (getenv("LZ4F_MI355X_PROF")) {                              // developer aid: why the windowed kernel stopped, if it did
+                if (sw.prof) {                              // developer aid: why the windowed kernel stopped, if it did
                     uint32_t dbg[3] = {0, 0, 0};
                     if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(dbg, fb, 12, hipMemcpyDeviceToHost) == hipSuccess)
                         fprintf(stderr, "k_decode_linked: fallback %u why %u block %u\n", dbg[0], dbg[1], dbg[2]);
                 }
             }
+            plan |= LZ4F_MI355X_PATH_FUSED;
             if (small)
                 hipLaunchKernelGGL(k_decode_blocks_fused<FzCfg<4>>, dim3(n_max), dim3(64 * 4), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
                                    (const ResultRec*)d_res, n_max, 0u, j.block_size, j.hist0, prof, only_if);
             else
                 hipLaunchKernelGGL(k_decode_blocks_fused<FzCfg<8>>, dim3(j.linked ? 1u : n_max), dim3(64 * 8), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
                                    (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, j.hist0, prof, only_if);
-        } else if (mode == '2') {
-            const size_t per_block = (size_t)j.block_size / 4 + 2;
-            if (desc.ensure((size_t)n_max * per_block * sizeof(SeqDesc)) || seqcnt.ensure((size_t)n_max * 8 + 64)) return make_err(LZ4F_ERROR_allocation_failed);
-            uint32_t* cnt = (uint32_t*)seqcnt.p; uint32_t* osz = cnt + n_max;
-            tick(8, false);
-            hipLaunchKernelGGL(k_parse_blocks, dim3((n_max + PK_WAVES - 1) / PK_WAVES), dim3(64 * PK_WAVES), 0, st, j.d_frame, (const BlockOut*)tbl,
-                               (const ResultRec*)d_res, n_max, j.block_size, j.linked ? 1u : 0u, (SeqDesc*)desc.p, cnt, osz);
-            tick(8, true);
-            tick(9, false);
-            hipLaunchKernelGGL(k_copy_blocks, dim3(j.linked ? 1u : n_max), dim3(64 * CK_WAVES), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
-                               (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, j.hist0, (const SeqDesc*)desc.p, (const uint32_t*)cnt,
-                               (const uint32_t*)osz, getenv("LZ4F_MI355X_DBG") ? (uint32_t)atoi(getenv("LZ4F_MI355X_DBG")) : 0u);
-            tick(9, true);
-        } else
+        } else {
+            plan |= LZ4F_MI355X_PATH_WAVE_PER_BLOCK;
             hipLaunchKernelGGL((k_decode_blocks<W>), dim3(grid), dim3(64 * W), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl, (const ResultRec*)d_res,
                                n_max, j.linked ? 1u : 0u, j.block_size, j.hist0);
+        }
         tick(6, true);
     }
     tick(7, false);
     hipLaunchKernelGGL(k_finish_decode, dim3(1), dim3(64), 0, st, j.d_dst, tbl, (ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size,
-                       j.block_checksum ? (const uint32_t*)bad.p : (const uint32_t*)nullptr);
+                       j.block_checksum ? (const uint32_t*)bad.p : (const uint32_t*)nullptr, plan, ix_flags);
+    if (j.content_checksum && !j.d_table && !j.table_in_place && !sw.no_content_check)      // (a whole frame was walked: res->consumed is behind its checksum word)
+        hipLaunchKernelGGL(k_xxh32_content, dim3(1), dim3(256), 0, st, (const uint8_t*)j.d_dst, 0ull, (uint8_t*)j.d_frame, (ResultRec*)d_res, 1u);
     tick(7, true);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -918,12 +931,12 @@ size_t lz4f_mi355x_dev_compressFrame(lz4f_mi355x_engine* e, void* d_dst, size_t 
     if (p.frameInfo.blockSizeID == 0) p.frameInfo.blockSizeID = LZ4F_max64KB;
     const size_t bs = block_size_of(p.frameInfo.blockSizeID);
     if (!bs) return make_err(LZ4F_ERROR_maxBlockSize_invalid);
-    if (p.frameInfo.contentChecksumFlag) { set_last_error("content checksum is host-only (serial XXH32): use lz4f_mi355x_compressFrame"); return make_err(LZ4F_ERROR_contentChecksumFlag_invalid); }
     if (p.compressionLevel > 2) { set_last_error("only the fast encoder (level <= 2) exists"); return make_err(LZ4F_ERROR_compressionLevel_invalid); }
     if (p.frameInfo.contentSize && p.frameInfo.contentSize != srcSize) return make_err(LZ4F_ERROR_frameSize_wrong);
     lz4f_mi355x_engine::CompressJob j; memset(&j, 0, sizeof(j));
     j.d_src = (const uint8_t*)d_src; j.src_size = srcSize; j.first_off = 0; j.block_size = (uint32_t)bs;
     j.linked = p.frameInfo.blockMode == LZ4F_blockLinked; j.block_checksum = p.frameInfo.blockChecksumFlag != 0; j.endmark = true;
+    j.content_checksum = p.frameInfo.contentChecksumFlag != 0;
     j.header_size = (uint32_t)write_frame_header(j.header, p);
     return e->launch_compress(j, (uint8_t*)d_dst, dstCapacity, d_result, d_table);
 }
@@ -955,12 +968,12 @@ size_t lz4f_mi355x_dev_compressFrameIndexed(lz4f_mi355x_engine* e, void* d_dst, 
     if (p.frameInfo.blockSizeID == 0) p.frameInfo.blockSizeID = LZ4F_max64KB;
     const size_t bs = block_size_of(p.frameInfo.blockSizeID);
     if (!bs) return make_err(LZ4F_ERROR_maxBlockSize_invalid);
-    if (p.frameInfo.contentChecksumFlag) { set_last_error("content checksum is host-only (serial XXH32): use lz4f_mi355x_compressFrame"); return make_err(LZ4F_ERROR_contentChecksumFlag_invalid); }
     if (p.compressionLevel > 2) { set_last_error("only the fast encoder (level <= 2) exists"); return make_err(LZ4F_ERROR_compressionLevel_invalid); }
     if (p.frameInfo.contentSize && p.frameInfo.contentSize != srcSize) return make_err(LZ4F_ERROR_frameSize_wrong);
     lz4f_mi355x_engine::CompressJob j; memset(&j, 0, sizeof(j));
     j.d_src = (const uint8_t*)d_src; j.src_size = srcSize; j.first_off = 0; j.block_size = (uint32_t)bs;
     j.linked = p.frameInfo.blockMode == LZ4F_blockLinked; j.block_checksum = p.frameInfo.blockChecksumFlag != 0; j.endmark = true;
+    j.content_checksum = p.frameInfo.contentChecksumFlag != 0;
     j.header_size = (uint32_t)write_frame_header(j.header, p);
     return e->launch_compress(j, (uint8_t*)d_dst, dstCapacity, d_result, d_table, d_index, inband ? LZ4F_MI355X_INBAND : (d_index ? indexCapacity : 0));
 }
@@ -988,8 +1001,8 @@ size_t lz4f_mi355x_dev_decompressFrame(lz4f_mi355x_engine* e, void* d_dst, size_
     uint8_t hdr[32]; memset(hdr, 0, sizeof(hdr));
     const size_t peek = frameCapacity < 19 ? frameCapacity : 19;
     if (peek < 7) return make_err(LZ4F_ERROR_frameHeader_incomplete);
-    TrailerFoot foot; memset(&foot, 0, sizeof(foot));              // the stream's last 16 bytes: this library's trailer, if it is one
-    const bool may_trail = frameCapacity >= 64 && ((uintptr_t)d_frame & 15) == 0 && !getenv("LZ4F_MI355X_NO_TRAILER");
+    TrailerFoot foot; memset(&foot, 0, sizeof(foot));              // the stream's last 32 bytes: this library's trailer, if it is one
+    const bool may_trail = frameCapacity >= 64 && ((uintptr_t)d_frame & 15) == 0 && !e->sw.no_trailer;
     if (hipMemcpyAsync(hdr, d_frame, peek, hipMemcpyDeviceToHost, (hipStream_t)e->stream) != hipSuccess ||
         (may_trail && hipMemcpyAsync(&foot, (const uint8_t*)d_frame + frameCapacity - sizeof(foot), sizeof(foot), hipMemcpyDeviceToHost, (hipStream_t)e->stream) != hipSuccess) ||
         hipStreamSynchronize((hipStream_t)e->stream) != hipSuccess) { set_last_error("header peek failed"); return make_err(LZ4F_ERROR_GENERIC); }
@@ -1002,6 +1015,7 @@ size_t lz4f_mi355x_dev_decompressFrame(lz4f_mi355x_engine* e, void* d_dst, size_
         size_t hs = parse_frame_header(hdr, peek, &ph);
         if (is_err(hs)) return hs;
         j.block_size = (uint32_t)ph.max_block; j.linked = ph.info.blockMode == LZ4F_blockLinked; j.block_checksum = ph.info.blockChecksumFlag != 0;
+        j.content_checksum = ph.info.contentChecksumFlag != 0;
         const uint64_t by_dst = dstCapacity / ph.max_block + 2;
         const uint64_t by_src = frameCapacity / 5 + 2;                // every block costs at least 5 frame bytes
         uint64_t mb = by_dst < by_src ? by_dst : by_src;
@@ -1014,7 +1028,7 @@ size_t lz4f_mi355x_dev_decompressFrame(lz4f_mi355x_engine* e, void* d_dst, size_
             if (ix_at + sizeof(foot) <= frameCapacity) {
                 j.hint_list = (const uint64_t*)((const uint8_t*)d_frame + list_at); j.hint_n = foot.n_blocks;      // (frame_cap stays the whole buffer: `at` is a claim)
                 const uint64_t ix_bytes = frameCapacity - sizeof(foot) - ix_at;
-                if (ix_bytes >= sizeof(IxHeader) && !j.linked) { j.d_index = (void*)((const uint8_t*)d_frame + ix_at); j.index_size = (size_t)ix_bytes; }
+                if (ix_bytes >= sizeof(IxHeader) && !j.linked && foot.total_seqs) { j.d_index = (void*)((const uint8_t*)d_frame + ix_at); j.index_size = (size_t)ix_bytes; j.ix_seqs = foot.total_seqs; j.ix_entries = foot.total_entries; }
             }
         }
     }

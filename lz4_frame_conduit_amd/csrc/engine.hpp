@@ -63,10 +63,14 @@ struct lz4f_mi355x_engine {
     lz4f::DevBuf desc, seqcnt;                             // two-kernel decode: sequence descriptors, per-block counts
     lz4f::DevBuf d_in, d_out;                              // staging for the host-pointer paths
     lz4f::PinBuf h_in, h_out, h_small;
-    // indexed decode: the last index header seen (copied back asynchronously) sizes the descriptor workspace of the next call
-    lz4f::PinBuf h_ix; void* ix_ev = nullptr; bool ix_pending = false; size_t ix_seq_cap = 0; uint32_t ix_entries_hint = 0;
-    bool ix_chain_hint = false;                            // the last indexed frame was judged dense on the device (most sequences on the match chain)
-    bool ix_dense_hint = false;                            // the last index header seen was of a stream of short sequences
+    // A-B and development switches: read from the environment ONCE, when the engine is made (engines of the host-pointer calls
+    // live in a pool: lz4f_mi355x_release_engines() makes the next ones read it again)
+    struct Switches {
+        bool no_index, no_selfindex, no_resolve, no_trace, no_doubling, trace_always, no_groups, no_window, serial_walk, no_trailer, no_content_check, prof, e1_sync;
+        int chain_gate; char decode_mode; unsigned e1_run, e1_solo, seed; unsigned long long wait_ticks;
+        void read();
+    } sw;
+    size_t ix_seq_cap = 0;                                 // indexed decode: descriptor workspace, in sequences (grow-only)
     bool  timing = false;
     void* ev[20] = {nullptr};      // hipEvent_t pairs (begin,end) per timing slot
     bool  ev_used[10] = {false};
@@ -76,6 +80,7 @@ struct lz4f_mi355x_engine {
     struct CompressJob {
         const uint8_t* d_src; uint64_t src_size; uint64_t first_off;
         uint32_t block_size; bool linked; bool block_checksum; bool endmark;
+        bool content_checksum;                                   // (with endmark) XXH32 of the whole input behind the EndMark: k_xxh32_content
         uint8_t header[20]; uint32_t header_size;
     };
     // returns 0 or an LZ4F error; d_res/d_table may be null (internal buffers are used)
@@ -85,10 +90,12 @@ struct lz4f_mi355x_engine {
         const uint8_t* d_frame; uint64_t frame_cap; uint8_t* d_dst; uint64_t dst_cap; uint64_t hist0;
         void* d_index; size_t index_size;   // sequence index written by launch_compress (optional; independent blocks only)
         uint32_t block_size; bool linked; bool block_checksum;
+        bool content_checksum;                                   // the frame's FLG asks for one: verified behind the decode (k_xxh32_content)
         const lz4f_mi355x_block* d_table; uint32_t n_blocks;     // when d_table != null the walk is skipped
         bool table_in_place;                                     // the engine's own table already holds n_blocks entries
         uint32_t max_blocks;                                     // grid bound when walking
         const uint64_t* hint_list; uint32_t hint_n;              // from the frame's trailer: where the size words should be (checked on the device)
+        uint32_t ix_seqs, ix_entries;                            // what the index says it holds (header / trailer footer: sizes the workspace; checked on the device)
     };
     size_t launch_decompress(const DecompressJob& j, lz4f_mi355x_result* d_res);
     size_t sync();

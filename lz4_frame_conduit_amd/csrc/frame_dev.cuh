@@ -7,7 +7,6 @@
 #pragma once
 #include "common.cuh"
 #include "decode.cuh"
-#include "decode_2k.cuh"
 #include "decode_fused.cuh"
 #include "decode_linked.cuh"
 #include "encode.cuh"
@@ -103,6 +102,95 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_xxh32_blocks(uint8_t* fra
     }
 }
 
+
+// One payload, FOUR waves: XXH32's four accumulators are independent chains until the end, so wave c of a 4-wave workgroup runs
+// accumulator c alone - a quarter of the scalar work per wave, the waves on different SIMDs.  Each wave fetches its own word of
+// every stripe (4 bytes per lane, 16 apart: the same cache lines for all four), two groups of 64 stripes ahead of the chain.
+// Few big payloads (4 MiB blocks: 256 of them per GiB; the content checksum: ONE) get ~4x out of this; many small ones fill
+// the machine with a wave each (wave_xxh32) and gain nothing.  `len` is 64 bits: the content checksum runs over the whole stream
+// (XXH32 adds the length modulo 2^32).  All 256 threads call it; the result is valid in wave 0.
+__device__ __forceinline__ uint32_t wg4_xxh32(const uint8_t* __restrict__ p, uint64_t len, uint32_t* acc4 /* LDS, 4 words */)
+{
+    const uint32_t lane = lane_id(), c = uni(threadIdx.x >> 6) & 3u;
+    const uint64_t nstripes = len >> 4;
+    if (len >= 16) {
+        uint32_t v = c == 0 ? XP1 + XP2 : c == 1 ? XP2 : c == 2 ? 0u : 0u - XP1;
+        const uint8_t* q = p + 4 * c;
+        auto fetch = [&](uint64_t s0) -> uint32_t {
+            const uint64_t s = s0 + lane;
+            return s < nstripes ? *(const u32_ua*)(q + s * 16) * XP2 : 0u;
+        };
+        uint32_t m = fetch(0), m_next = fetch(WAVE);
+        for (uint64_t s0 = 0; s0 < nstripes; s0 += WAVE) {
+            const uint32_t m_after = fetch(s0 + 2 * WAVE);
+            const uint32_t n = (nstripes - s0 < WAVE) ? (uint32_t)(nstripes - s0) : WAVE;     // uniform
+            if (n == WAVE) {
+#pragma unroll
+                for (int i = 0; i < WAVE; i++) v = rotl32(v + __builtin_amdgcn_readlane(m, i), 13) * XP1;
+            } else {
+                for (uint32_t i = 0; i < n; i++) v = rotl32(v + __builtin_amdgcn_readlane(m, i), 13) * XP1;
+            }
+            m = m_next; m_next = m_after;
+        }
+        if (lane == 0) acc4[c] = v;
+    }
+    __syncthreads();
+    uint32_t h = XP5;
+    if (len >= 16) h = rotl32(acc4[0], 1) + rotl32(acc4[1], 7) + rotl32(acc4[2], 12) + rotl32(acc4[3], 18);
+    h += (uint32_t)len;
+    const uint64_t done = nstripes << 4;
+    h = xxh32_finish(h, p + done, (uint32_t)(len - done));
+    __syncthreads();
+    return h;
+}
+
+constexpr uint32_t XXH_WG_BELOW = 4096;         // fewer blocks than this: a workgroup per block
+// k_xxh32_blocks with a workgroup per block (see wg4_xxh32): the host takes it when there are too few blocks for a wave each
+__global__ __launch_bounds__(256) void k_xxh32_blocks4(uint8_t* frame, BlockOut* __restrict__ table, const ResultRec* __restrict__ res,
+                                                       uint32_t n_max, uint32_t mode, uint32_t* __restrict__ bad)
+{
+    __shared__ uint32_t acc4[4];
+    const uint32_t b = blockIdx.x;
+    const uint32_t n = res ? res->n_blocks : n_max;
+    if (b >= n || b >= n_max) return;
+    if (res && res->status != ST_OK) return;
+    const uint64_t off = table[b].src_off;
+    const uint32_t len = table[b].word & 0x7FFFFFFFu;
+    const uint32_t h = wg4_xxh32(frame + off, len, acc4);
+    if (threadIdx.x == 0) {
+        uint8_t* c = frame + off + len;
+        if (mode == 0) { c[0] = (uint8_t)h; c[1] = (uint8_t)(h >> 8); c[2] = (uint8_t)(h >> 16); c[3] = (uint8_t)(h >> 24); }
+        else {
+            const uint32_t stored = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
+            if (stored != h) atomicMin(bad, b);
+        }
+    }
+}
+
+// The content checksum (Frame format "Content checksum"; LZ4F_compressEnd / LZ4F_decompress at the frame's end): XXH32 of the whole
+// stream, one chain by construction.  One workgroup, ~4x a single wave (measured rate in DESIGN.md) - still seconds per GiB beside a
+// codec that takes milliseconds, so a frame asks for it by its FLG bit and pays for it; the default prefs of the reference's
+// conduit (Conduit.hsc:205) leave it off.
+//   mode 0 (compress): `data` is the input; the word goes to the frame's last 4 bytes (res->size counts them already).
+//   mode 1 (decompress): `data` is the decoded output, res->size its length; the stored word is the 4 bytes in front of
+//                        res->consumed; a mismatch sets ERROR_contentChecksum_invalid (18).
+__global__ __launch_bounds__(256) void k_xxh32_content(const uint8_t* __restrict__ data, uint64_t data_len, uint8_t* frame, ResultRec* __restrict__ res, uint32_t mode)
+{
+    __shared__ uint32_t acc4[4];
+    if (res->status != ST_OK) return;
+    if (mode == 1 && !((res->flags >> 2) & 1)) return;                 // (the frame has none)
+    const uint64_t len = mode == 0 ? data_len : res->size;
+    const uint32_t h = wg4_xxh32(data, len, acc4);
+    if (threadIdx.x == 0) {
+        uint8_t* c = frame + (mode == 0 ? res->size : res->consumed) - 4;
+        if (mode == 0) { c[0] = (uint8_t)h; c[1] = (uint8_t)(h >> 8); c[2] = (uint8_t)(h >> 16); c[3] = (uint8_t)(h >> 24); }
+        else {
+            const uint32_t stored = (uint32_t)c[0] | ((uint32_t)c[1] << 8) | ((uint32_t)c[2] << 16) | ((uint32_t)c[3] << 24);
+            if (stored != h) res->status = 18;                         // contentChecksum_invalid
+        }
+    }
+}
+
 // ------------------------------- frame walk -----------------------------------------------------
 __device__ __forceinline__ uint32_t rd32_any(const uint8_t* p)
 {
@@ -169,7 +257,7 @@ __global__ void k_walk_frame(const uint8_t* __restrict__ frame, uint64_t frame_c
         pos += (uint64_t)csz + 4 * bck;
         n++;
     }
-    if ((flg >> 2) & 1) { if (frame_cap - pos < 4) return fail(12); pos += 4; }   // content checksum: skipped, see header
+    if ((flg >> 2) & 1) { if (frame_cap - pos < 4) return fail(12); pos += 4; }   // content checksum: verified behind the decode (k_xxh32_content)
     r.n_blocks = n; r.consumed = pos; r.size = content;             // size = declared content size until decode fills it
     *res = r;
 }
@@ -424,13 +512,14 @@ __global__ void k_walk_verdict(const uint8_t* __restrict__ frame, uint64_t frame
 // ------------------------------- the frame's trailer (in-band block list + sequence index) ------
 // What this library's own decoder can use - where every block's size word sits, and the compressor's sequence index (encode.cuh) -
 // travels IN the byte stream, as a skippable frame (magic 0x184D2A5E) right behind the LZ4 frame: liblz4, the `lz4` tool and
-// the reference's decompress conduit skip or never reach it, this decoder finds it from its last 16 bytes.
+// the reference's decompress conduit skip or never reach it, this decoder finds it from its last 32 bytes.
 //   frame | 5E 2A 4D 18 | u32 size | pad to 16 | u64 word_pos[n_blocks (+1 to even)] | index (IxHeader ... entries) or nothing |
-//         | footer: u32 'LZIX', u32 n_blocks, u64 trailer bytes (from the magic on)
+//         | footer (32 bytes): u32 sequences, u32 entries of the index (for sizing the decoder's workspace), 8 zero bytes,
+//         |                    u32 'LZIX', u32 n_blocks, u64 trailer bytes (from the magic on)
 // Nothing in it is trusted: the positions are accepted only if they are the chain the size words themselves form (k_walk_link /
 // k_walk_verdict, as for the candidates of the parallel walk), the index only as far as k_parse_indexed can follow it in the payload.
 constexpr uint32_t TR_MAGIC = 0x184D2A5Eu, TR_FOOT = 0x58495A4Cu;
-struct TrailerFoot { uint32_t magic, n_blocks; uint64_t total; };
+struct TrailerFoot { uint32_t total_seqs, total_entries, pad0, pad1, magic, n_blocks; uint64_t total; };      // 32 bytes; the last 16 identify it
 struct TrailerPlan { uint64_t at, list_at, ix_at, ix_bytes, total; uint32_t n_list, ok; };
 
 __global__ void k_trailer_plan(uint8_t* __restrict__ dst, uint64_t dst_cap, ResultRec* __restrict__ res, uint32_t n_blocks, const void* __restrict__ ix,
@@ -454,7 +543,7 @@ __global__ void k_trailer_plan(uint8_t* __restrict__ dst, uint64_t dst_cap, Resu
             const uint32_t sz = (uint32_t)(p.total - 8);
             t[0] = 0x5E; t[1] = 0x2A; t[2] = 0x4D; t[3] = 0x18; t[4] = (uint8_t)sz; t[5] = (uint8_t)(sz >> 8); t[6] = (uint8_t)(sz >> 16); t[7] = (uint8_t)(sz >> 24);
             for (uint64_t q = F + 8; q < p.list_at; q++) dst[q] = 0;
-            TrailerFoot f{TR_FOOT, n_blocks, p.total};
+            TrailerFoot f{with_ix ? hd->total_seqs : 0u, with_ix ? hd->total_entries : 0u, 0u, 0u, TR_FOOT, n_blocks, p.total};
             memcpy(dst + p.ix_at + p.ix_bytes, &f, sizeof(f));
             res->size = F + p.total;
         }
@@ -531,8 +620,11 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_decode_blocks(const uint8
 
 // totals + status; compacts the output if a non-final block of an independent frame decoded short
 __global__ __launch_bounds__(64) void k_finish_decode(uint8_t* dst, BlockOut* __restrict__ table, ResultRec* res, uint32_t n_max,
-                                                      uint32_t linked, uint32_t block_size, const uint32_t* __restrict__ bad_ck)
+                                                      uint32_t linked, uint32_t block_size, const uint32_t* __restrict__ bad_ck,
+                                                      uint32_t plan = 0, const uint32_t* __restrict__ ix_flags = nullptr)
 {
+    // which way the call went (lz4f_mi355x.h: LZ4F_MI355X_PATH_*): what the host launched, and whether the indexed kernels gave up
+    if (lane_id() == 0) res->flags = (res->flags & 0xFFFu) | (plan << 12) | ((ix_flags && *ix_flags) ? (LZ4F_MI355X_PATH_INDEX_DROPPED << 12) : 0u);
     if (res->status != ST_OK) return;
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
     const uint32_t lane = lane_id();

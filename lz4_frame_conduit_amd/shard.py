@@ -72,3 +72,20 @@ def assemble_frame(header: bytes, words: Sequence[int], payloads: Sequence[bytes
             out.append(int(checksums[i]).to_bytes(4, "little"))
     out.append(b"\x00\x00\x00\x00")
     return b"".join(out)
+
+
+def contiguous_blocks(n_blocks: int, rank: int, world: int) -> "tuple[int, int]":
+    """[lo, hi): rank's contiguous run of blocks (runs of K blocks per GPU keep the copies large)."""
+    per, extra = divmod(n_blocks, world)
+    lo = rank * per + min(rank, extra)
+    return lo, lo + per + (1 if rank < extra else 0)
+
+
+def all_gather_sizes(mine: int, device: "torch.device | str" = "cpu") -> List[int]:
+    """Every rank's byte count, on every rank (8 B x world: with the block words the only numbers that cross ranks)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return [int(mine)]
+    t = torch.zeros(dist.get_world_size(), dtype=torch.int64, device=device)
+    t[dist.get_rank()] = int(mine)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(x) for x in t.tolist()]

@@ -73,3 +73,70 @@ def test_round_robin_blocks_world2_gloo():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _hip_worker(rank: int, world: int, port: int, outq):
+    """One process per GPU: rank r encodes its contiguous run of blocks on device r through the C ABI (the HIP path, no oracle in
+    the product), the ranks exchange nothing but the bodies' sizes and bytes, rank 0 puts header | body 0 | body 1 | EndMark
+    together.  liblz4 (the oracle, as the checker) and the library itself must decode that to the input."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        import oracle
+        from lz4_frame_conduit_amd import conduit, datagen, shard
+        from lz4_frame_conduit_amd.device import Engine
+        bs = 4 << 20
+        data = datagen.synth50(64 << 20, 99)
+        n_blocks = len(data) // bs
+        lo, hi = shard.contiguous_blocks(n_blocks, rank, world)
+        torch.cuda.set_device(rank)
+        eng = Engine(rank)
+        prefs = conduit.make_preferences(blockSizeID=7, blockMode=1)
+        src = torch.from_numpy(data[lo * bs:hi * bs].copy()).cuda(rank)
+        frame = torch.empty(eng.frame_bound(src.numel(), prefs), dtype=torch.uint8, device="cuda:%d" % rank)
+        eng.compress_async(src, frame, prefs)
+        r = eng.result()
+        body = frame[7:r.size - 4].cpu().numpy().tobytes()              # without the 7-byte header and the EndMark
+        sizes = shard.all_gather_sizes(len(body))                        # the only numbers that cross ranks
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(body, gathered, dst=0)
+        shard.barrier_all()
+        if rank == 0:
+            assert sizes == [len(b) for b in gathered]
+            whole = oracle.header_bytes(oracle.mkprefs(bsid=7, indep=1)) + b"".join(gathered) + bytes(4)
+            out, used = oracle.decompress_frame(whole, cap=len(data) + 64)
+            assert used == len(whole) and out == data.tobytes()
+            dev = torch.from_numpy(np.frombuffer(whole, dtype=np.uint8).copy()).cuda(0)
+            back = torch.zeros(len(data), dtype=torch.uint8, device="cuda:0")
+            eng.decompress_frame_async(dev, dev.numel(), back)
+            r2 = eng.result()
+            assert r2.size == len(data) and back.cpu().numpy().tobytes() == data.tobytes()
+        eng.close()
+        outq.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        outq.put((rank, "FAIL %r %s" % (e, traceback.format_exc()[-600:])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_contiguous_runs_world2_hip_path():
+    """The same sharding with the HIP codec on two GPUs (skipped where fewer than two are visible - the round-end GPU box has one)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import oracle
+    oracle.build()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_hip_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

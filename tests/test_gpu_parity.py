@@ -50,6 +50,9 @@ def gpu_compress_frame(L, data: bytes, prefs) -> bytes:
 
 PREF_SETS = {"default": {}, "cli": dict(bsid=7, indep=1, cck=1), "cli_bck": dict(bsid=7, indep=1, cck=1, bck=1),
              "indep64k_bck": dict(bsid=4, indep=1, bck=1), "linked256k_cck": dict(bsid=5, indep=0, cck=1)}
+# result.flags >> 12 (include/lz4f_mi355x.h: LZ4F_MI355X_PATH_*)
+PATH = dict(table=0x001, trailer=0x002, parallel_walk=0x004, indexed=0x008, self_index=0x010, doubling=0x020, hops=0x040, window=0x080, fused=0x100,
+            wave_per_block=0x200, dropped=0x400)
 SMALL_INPUTS = ["hello20", "empty", "rep42", "ints", "hello100k", "tiny12", "tiny13"]
 
 
@@ -530,6 +533,7 @@ def test_linked_frames_windowed_and_fallback(L, named_inputs):
     # kernel (what the former falls back to, and takes dense frames by itself), the single-workgroup generic kernel
     for env in ({}, {"LZ4F_MI355X_NO_SELFINDEX": "1"}, {"LZ4F_MI355X_NO_SELFINDEX": "1", "LZ4F_MI355X_NO_WINDOW": "1"}):
         os.environ.update(env)
+        L.lz4f_mi355x_release_engines()                                       # (an engine reads its switches when it is made)
         try:
             for i, (frame, want) in enumerate(cases):
                 out, used = gpu_decompress_frame(L, frame, len(want) + 8)
@@ -537,6 +541,7 @@ def test_linked_frames_windowed_and_fallback(L, named_inputs):
         finally:
             for k in env:
                 os.environ.pop(k, None)
+            L.lz4f_mi355x_release_engines()
     # malformed linked frames: same verdicts as the oracle
     base = cases[0][0]
     for pos in (200, 5000, 70000, 140000, len(base) // 2):
@@ -781,6 +786,9 @@ def test_parallel_walk_of_device_frames(L, monkeypatch):
     import torch
     from lz4_frame_conduit_amd.device import Engine
     eng = Engine(0)
+    monkeypatch.setenv("LZ4F_MI355X_SERIAL_WALK", "1")                                     # (switches are read when an engine is made)
+    eng_serial = Engine(0)
+    monkeypatch.delenv("LZ4F_MI355X_SERIAL_WALK")
     rng = np.random.default_rng(31)
     ints = rng.integers(0, 40000, 3 << 20, dtype=np.uint32).view(np.uint8)                 # 12 MiB, every word a plausible size word
     inputs = [("synth50", datagen.synth50(24 << 20, 5)), ("text", datagen.synth_text(20 << 20, 3)), ("small ints", ints),
@@ -793,15 +801,15 @@ def test_parallel_walk_of_device_frames(L, monkeypatch):
             src = torch.from_numpy(data).cuda()
             results = []
             for serial in (False, True):
-                if serial: monkeypatch.setenv("LZ4F_MI355X_SERIAL_WALK", "1")
-                else: monkeypatch.delenv("LZ4F_MI355X_SERIAL_WALK", raising=False)
+                en = eng_serial if serial else eng
                 back = torch.zeros_like(src)
-                eng.decompress_frame_async(dev, dev.numel(), back)
-                r = eng.result()
+                en.decompress_frame_async(dev, dev.numel(), back)
+                r = en.result()
                 assert r.size == src.numel() and r.consumed == len(ref) and torch.equal(back, src), (name, kw, serial)
+                assert bool((r.flags >> 12) & PATH["parallel_walk"]) == (not serial and len(ref) >= (1 << 20)), (name, kw, serial, hex(r.flags))
                 results.append((int(r.n_blocks), int(r.consumed)))
             assert results[0] == results[1], (name, kw, results)
-    eng.close()
+    eng.close(); eng_serial.close()
 
 
 @pytest.mark.gpu
@@ -833,14 +841,16 @@ def test_inband_trailer_interop_and_robustness(L):
         assert r2.size == src.numel() and r2.consumed == used and torch.equal(back, src), name
         # damage: bytes of the block list, of the index, of the footer; a footer that names another block count; a cut trailer
         tr = len(stream) - used
-        for trial in range(10):
+        for trial in range(12):
             bad = bytearray(stream)
             if trial < 6:
                 for _ in range(1 + trial): bad[used + int(rng.integers(8, tr))] ^= int(rng.integers(1, 256))
             elif trial == 6: bad[-12:-8] = (int.from_bytes(bad[-12:-8], "little") + 1).to_bytes(4, "little")
             elif trial == 7: bad[-8:] = (int.from_bytes(bad[-8:], "little") - 16).to_bytes(8, "little")
             elif trial == 8: bad = bad[:len(bad) - 5000] if tr > 6000 else bad[:-8]
-            else: bad[used + 16:used + 16 + 64] = bytes(64)
+            elif trial == 9: bad[used + 16:used + 16 + 64] = bytes(64)
+            elif trial == 10: bad[-32:-28] = (1).to_bytes(4, "little")                     # "one sequence": the workspace it sizes is too small, the device notices
+            else: bad[-32:-24] = b"\xf0\xff\xff\xff" * 2                                 # counts the index cannot hold
             dev = torch.zeros(len(bad) + 32, dtype=torch.uint8, device="cuda")
             dev[:len(bad)] = torch.from_numpy(np.frombuffer(bytes(bad), dtype=np.uint8).copy()).cuda()
             back.zero_()
@@ -848,3 +858,176 @@ def test_inband_trailer_interop_and_robustness(L):
             r3 = eng.result()
             assert r3.size == src.numel() and torch.equal(back, src), (name, trial)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_decode_path_by_input_class(L):
+    """Which kernels a decompress call launches is a function of the call alone - the arguments, the frame's header and trailer,
+    the switches the engine was made with - and is reported in result.flags (LZ4F_MI355X_PATH_*).  One case per input class,
+    run in two different orders on one engine and on a fresh engine: the same path every time, and the source's bytes."""
+    import torch
+    from lz4_frame_conduit_amd.device import Engine
+    P = PATH
+    s50, text = datagen.synth50(16 << 20, 21), datagen.synth_text(8 << 20, 22)
+    def foreign(data, **kw): return oracle.conduit_compress(data.tobytes(), oracle.mkprefs(**kw))
+    cases = {}      # name -> (kind, data, prefs kw, must have, must not have)
+    cases["foreign 4M independent"] = ("foreign", s50, dict(bsid=7, indep=1), P["fused"], P["table"] | P["trailer"] | P["parallel_walk"] | P["indexed"] | P["wave_per_block"] | P["window"])
+    cases["foreign 64K independent"] = ("foreign", s50, dict(bsid=4, indep=1), P["parallel_walk"] | P["wave_per_block"], P["table"] | P["trailer"] | P["indexed"] | P["fused"])
+    cases["foreign 64K independent, short"] = ("foreign", s50[:300000], dict(bsid=4, indep=1), P["wave_per_block"], P["parallel_walk"] | P["trailer"] | P["indexed"] | P["fused"])
+    cases["foreign 64K linked"] = ("foreign", s50, dict(bsid=4, indep=0), P["self_index"] | P["indexed"] | P["window"] | P["fused"], P["table"] | P["trailer"] | P["wave_per_block"] | P["dropped"])
+    cases["foreign 4M linked text"] = ("foreign", text, dict(bsid=7, indep=0), P["self_index"] | P["indexed"] | P["doubling"], P["table"] | P["trailer"] | P["hops"])
+    cases["in-band 4M"] = ("inband", s50, dict(bsid=7, indep=1), P["trailer"] | P["indexed"] | P["fused"], P["table"] | P["parallel_walk"] | P["self_index"] | P["doubling"] | P["dropped"])
+    cases["in-band 64K"] = ("inband", s50, dict(bsid=4, indep=1), P["trailer"] | P["wave_per_block"], P["table"] | P["parallel_walk"] | P["indexed"] | P["fused"])
+    # (text has more sequences than an index of the recommended size holds: the compressor marks it unusable, the trailer carries the block list alone)
+    cases["in-band 4M text"] = ("inband", text, dict(bsid=7, indep=1), P["trailer"] | P["fused"], P["table"] | P["indexed"] | P["hops"] | P["self_index"] | P["parallel_walk"])
+    cases["table + index 4M"] = ("indexed", s50, dict(bsid=7, indep=1), P["table"] | P["indexed"] | P["fused"], P["trailer"] | P["parallel_walk"] | P["self_index"] | P["dropped"])
+    cases["table 4M"] = ("table", s50, dict(bsid=7, indep=1), P["table"] | P["fused"], P["trailer"] | P["parallel_walk"] | P["indexed"])
+    made = {}
+    def prepare(eng, name):
+        kind, data, kw, _, _ = cases[name]
+        src = torch.from_numpy(data).cuda()
+        p = prefs_of(kw)
+        if kind == "foreign":
+            fr = foreign(data, **kw)
+            return dict(src=src, frame=torch.from_numpy(np.frombuffer(fr, dtype=np.uint8).copy()).cuda(), size=len(fr))
+        bs = 1 << (8 + 2 * kw["bsid"]); nb = (src.numel() + bs - 1) // bs
+        frame = torch.empty(eng.frame_bound_inband(src.numel(), p), dtype=torch.uint8, device="cuda")
+        if kind == "inband":
+            eng.compress_async(src, frame, p, inband=True)
+            return dict(src=src, frame=frame, size=int(eng.result().size))
+        table, index = eng.new_table(nb), eng.new_index(src.numel(), p)
+        eng.compress_async(src, frame, p, table, index)
+        return dict(src=src, frame=frame, size=int(eng.result().size), table=table, index=index if kind == "indexed" else None, nb=nb, info=p.frameInfo)
+    def run(eng, name):
+        m = made[name]
+        back = torch.zeros_like(m["src"])
+        if "table" in m: eng.decompress_blocks_async(m["frame"], m["size"], back, m["table"], m["nb"], m["info"], m["index"])
+        else: eng.decompress_frame_async(m["frame"], m["size"], back)
+        r = eng.result()
+        assert r.size == m["src"].numel() and torch.equal(back, m["src"]), name
+        return int(r.flags) >> 12
+    eng = Engine(0)
+    for name in cases: made[name] = prepare(eng, name)
+    names = list(cases)
+    seen = {}
+    for order in (names, names[::-1], names[3:] + names[:3]):
+        for name in order:
+            path = run(eng, name)
+            _, _, _, must, must_not = cases[name]
+            assert path & must == must and path & must_not == 0, (name, hex(path), hex(must), hex(must_not))
+            assert seen.setdefault(name, path) == path, (name, hex(path), hex(seen[name]))       # not a function of what ran before
+    eng.close()
+    for name in names[::2]:                                                     # nor of the engine's age
+        fresh = Engine(0)
+        assert run(fresh, name) == seen[name], name
+        fresh.close()
+
+
+@pytest.mark.gpu
+def test_linked_wait_budget_expires(L, monkeypatch):
+    """A workgroup of a linked frame that waits for the one in front has a budget derived from the frame's size (engine.hip:
+    wait_ticks).  With a budget of one tick every wait expires at once: the indexed kernels give up, say so
+    (LZ4F_MI355X_PATH_INDEX_DROPPED), and the kernels behind them still produce liblz4's bytes."""
+    import torch
+    from lz4_frame_conduit_amd.device import Engine
+    monkeypatch.setenv("LZ4F_MI355X_WAIT_TICKS", "1")
+    eng = Engine(0)
+    monkeypatch.delenv("LZ4F_MI355X_WAIT_TICKS")
+    ref_eng = Engine(0)
+    dropped = 0
+    # a second block that is done in no time but needs the first one's last bytes (its own tail repeated: one match into the block
+    # in front, then matches that read what that one will write): its workgroup has to wait for the first block's
+    d0 = datagen.synth50(4 << 20, 24).tobytes()
+    waits = d0 + d0[-2000:] * ((4 << 20) // 2000)
+    for data, kw in ((waits, dict(bsid=7, indep=0)), (datagen.structured(24 << 20, 500), dict(bsid=7, indep=0)), (datagen.structured(6 << 20, 501), dict(bsid=4, indep=0)),
+                     (datagen.synth50(12 << 20, 23).tobytes(), dict(bsid=6, indep=0))):
+        fr = oracle.conduit_compress(data, oracle.mkprefs(**kw))
+        dev = torch.from_numpy(np.frombuffer(fr, dtype=np.uint8).copy()).cuda()
+        want = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+        for en in (eng, ref_eng):
+            back = torch.zeros_like(want)
+            en.decompress_frame_async(dev, dev.numel(), back)
+            r = en.result()
+            assert r.size == want.numel() and torch.equal(back, want), kw
+            if en is eng: dropped += ((r.flags >> 12) & PATH["dropped"]) != 0
+            else: assert ((r.flags >> 12) & PATH["dropped"]) == 0, kw
+    assert dropped >= 1
+    eng.close(); ref_eng.close()
+
+
+@pytest.mark.gpu
+def test_device_path_content_checksum(L):
+    """Frames with a content checksum on the device-pointer path (Frame format "Content checksum"; liblz4 writes it in
+    LZ4F_compressEnd and checks it at the end of LZ4F_decompress).  Compress: the oracle (liblz4) accepts the frame, which it
+    would not with a wrong word.  Decompress: liblz4's frames decode; a flipped checksum bit, or a flipped bit in a stored
+    block (nothing else would notice), gives ERROR_contentChecksum_invalid.  Also with block checksums (the 4-wave kernel for
+    few blocks, the wave-per-block one for many) and with the in-band trailer behind the checksum word."""
+    import torch
+    from lz4_frame_conduit_amd.device import Engine, DeviceCodecError
+    eng = Engine(0)
+    rng = np.random.default_rng(77)
+    noise = rng.integers(0, 256, 3 << 20, dtype=np.uint8)
+    inputs = [("synth50", np.concatenate([datagen.synth50(9 << 20, 31), noise[:12345]])), ("noise", noise), ("empty", np.zeros(0, dtype=np.uint8)), ("tiny", noise[:13].copy()),
+              ("text", datagen.synth_text(5 << 20, 6))]
+    for name, data in inputs:
+        for kw in (dict(bsid=7, indep=1, cck=1), dict(bsid=4, indep=1, cck=1, bck=1), dict(bsid=6, indep=0, cck=1), dict(bsid=7, indep=1, cck=1, bck=1)):
+            p = prefs_of(kw)
+            src = torch.from_numpy(data).cuda() if len(data) else torch.zeros(0, dtype=torch.uint8, device="cuda")
+            for inband in (False, True):
+                if inband and len(data) == 0: continue
+                frame = torch.empty(eng.frame_bound_inband(len(data), p) + 64, dtype=torch.uint8, device="cuda")
+                eng.compress_async(src, frame, p, inband=inband)
+                r = eng.result()
+                stream = frame[:r.size].cpu().numpy().tobytes()
+                out, used = oracle.decompress_frame(stream, cap=len(data) + 64)          # liblz4 checks the word
+                assert out == data.tobytes() and (used == len(stream)) == (not inband), (name, kw, inband)
+                back = torch.zeros(len(data) + 16, dtype=torch.uint8, device="cuda")
+                eng.decompress_frame_async(frame, int(r.size), back)
+                r2 = eng.result()
+                assert r2.size == len(data) and r2.consumed == used and back[:len(data)].cpu().numpy().tobytes() == data.tobytes(), (name, kw, inband)
+            # liblz4's own frame, then the same frame with a wrong checksum word
+            ref = oracle.conduit_compress(data.tobytes(), oracle.mkprefs(**kw))
+            for flip in (None, len(ref) - 2):
+                bad = bytearray(ref)
+                if flip is not None: bad[flip] ^= 0x10
+                dev = torch.from_numpy(np.frombuffer(bytes(bad) + bytes(32), dtype=np.uint8).copy()).cuda()
+                back = torch.zeros(len(data) + 16, dtype=torch.uint8, device="cuda")
+                eng.decompress_frame_async(dev, len(bad), back)
+                if flip is None:
+                    r3 = eng.result()
+                    assert r3.size == len(data) and r3.consumed == len(ref) and back[:len(data)].cpu().numpy().tobytes() == data.tobytes(), (name, kw)
+                else:
+                    with pytest.raises(DeviceCodecError, match="contentChecksum_invalid"): eng.result()
+    # a flipped bit inside a stored block of a frame without block checksums: only the content checksum can tell
+    ref = bytearray(oracle.conduit_compress(noise.tobytes(), oracle.mkprefs(bsid=5, indep=1, cck=1)))
+    ref[len(ref) // 2 + 1000] ^= 1                                           # (inside block 6's stored payload)
+    dev = torch.from_numpy(np.frombuffer(bytes(ref), dtype=np.uint8).copy()).cuda()
+    back = torch.zeros(len(noise) + 16, dtype=torch.uint8, device="cuda")
+    eng.decompress_frame_async(dev, len(ref), back)
+    with pytest.raises(DeviceCodecError, match="contentChecksum_invalid"): eng.result()
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_bulk_calls_over_several_gpus(L):
+    """lz4f_mi355x_use_devices: the host-pointer bulk calls deal their slabs over that many GPUs (blocks of an independent-block
+    frame need nothing from each other: no collective, the host puts the output in order).  With one GPU visible only the
+    argument checks run; with two or more the round trip goes over two and must give liblz4-decodable frames and the input back."""
+    import torch
+    have = torch.cuda.device_count()
+    assert L.lz4f_mi355x_device_count() == have
+    assert L.LZ4F_isError(L.lz4f_mi355x_use_devices(0)) and L.LZ4F_isError(L.lz4f_mi355x_use_devices(have + 1))
+    assert L.lz4f_mi355x_use_devices(1) == 0
+    if have < 2:
+        pytest.skip("one GPU visible: the two-GPU round trip needs two")
+    data = datagen.synth50(300 << 20, 41).tobytes()
+    try:
+        assert L.lz4f_mi355x_use_devices(2) == 0
+        for kw in (dict(bsid=7, indep=1), dict(bsid=4, indep=1, bck=1), dict(bsid=4, indep=0)):
+            frame = gpu_compress_frame(L, data, prefs_of(kw))
+            out, used = oracle.decompress_frame(frame, cap=len(data) + 64)
+            assert used == len(frame) and out == data, kw
+            back, used2 = gpu_decompress_frame(L, frame, len(data) + 8)
+            assert used2 == len(frame) and back == data, kw
+    finally:
+        L.lz4f_mi355x_use_devices(1)
