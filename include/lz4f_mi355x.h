@@ -231,8 +231,8 @@ LZ4F_MI355X_API size_t lz4f_mi355x_dev_workspace_size(size_t srcSize, const LZ4F
  * >= srcSize/blockSize+1 entries) receives the block table, which dev_decompressBlocks accepts
  * back to skip the serial walk over the size words.
  * Content checksum (prefs->frameInfo.contentChecksumFlag): XXH32 over the whole input is one
- * dependent chain, so ONE workgroup computes it (k_xxh32_content: the four accumulators on four
- * waves) at a few GB/s - far below the codec; the word lands behind the EndMark as liblz4's does.  */
+ * dependent chain, so ONE wave computes it (k_xxh32_content: the four accumulators as four
+ * lanes) at ~2.4 GB/s - far below the codec; the word lands behind the EndMark as liblz4's does.  */
 LZ4F_MI355X_API size_t lz4f_mi355x_dev_compressFrame(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity,
                                                      const void* d_src, size_t srcSize, const LZ4F_preferences_t* prefs,
                                                      lz4f_mi355x_result* d_result, lz4f_mi355x_block* d_table);
@@ -240,7 +240,7 @@ LZ4F_MI355X_API size_t lz4f_mi355x_dev_compressFrame(lz4f_mi355x_engine* e, void
 /* First frame at d_frame[0..frameCapacity) -> d_dst.  Peeks the 7..19 header bytes (one small
  * device->host copy), then everything is asynchronous: a walk kernel chases the size words, block
  * checksums are verified on the GPU, blocks are decoded.  A content checksum present in the
- * frame is verified behind the decode (same single workgroup as above; a mismatch gives
+ * frame is verified behind the decode (same single wave as above; a mismatch gives
  * ERROR_contentChecksum_invalid in result.status); an engine made with
  * LZ4F_MI355X_NO_CONTENT_CHECK set in the environment skips that, as liblz4 >= 1.9.4 can
  * (LZ4F_decompressOptions_t.skipChecksums).                                                   */

@@ -285,8 +285,8 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
         tick(2, true);
         if (j.block_checksum) {
             tick(3, false);
-            if (g.n_blocks < XXH_WG_BELOW)                             // few big blocks: four waves each (wg4_xxh32)
-                hipLaunchKernelGGL(k_xxh32_blocks4, dim3(g.n_blocks), dim3(256), 0, st, d_dst, (BlockOut*)d_table, (const ResultRec*)d_res, g.n_blocks, 0u, (uint32_t*)nullptr);
+            if (g.n_blocks < XXH_LANE4_BELOW)                          // few big blocks: the four accumulators as four lanes (lane4_xxh32)
+                hipLaunchKernelGGL((k_xxh32_blocks4<1>), dim3(g.n_blocks), dim3(64), 0, st, d_dst, (BlockOut*)d_table, (const ResultRec*)d_res, g.n_blocks, 0u, (uint32_t*)nullptr);
             else
             hipLaunchKernelGGL((k_xxh32_blocks<W>), dim3((g.n_blocks + W - 1) / W), dim3(64 * W), 0, st, d_dst, (BlockOut*)d_table,
                                (const ResultRec*)d_res, g.n_blocks, 0u, (uint32_t*)nullptr);
@@ -294,7 +294,7 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
         }
     }
     if (j.endmark && j.content_checksum)                              // (one chain over the whole input: see k_xxh32_content for what that costs)
-        hipLaunchKernelGGL(k_xxh32_content, dim3(1), dim3(256), 0, st, j.d_src + j.first_off, (uint64_t)(j.src_size - j.first_off), d_dst, (ResultRec*)d_res, 0u);
+        hipLaunchKernelGGL(k_xxh32_content, dim3(1), dim3(64), 0, st, j.d_src + j.first_off, (uint64_t)(j.src_size - j.first_off), d_dst, (ResultRec*)d_res, 0u);
     if (inband && g.n_blocks) {
         TrailerPlan* plan = (TrailerPlan*)((uint8_t*)res.p + sizeof(ResultRec) + 32);
         hipLaunchKernelGGL(k_trailer_plan, dim3(1), dim3(64), 0, st, d_dst, dst_cap, (ResultRec*)d_res, g.n_blocks, (const void*)d_index,
@@ -376,8 +376,8 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
     if (n_max) {
         if (j.block_checksum) {
             tick(5, false);
-            if (n_max < XXH_WG_BELOW)
-                hipLaunchKernelGGL(k_xxh32_blocks4, dim3(n_max), dim3(256), 0, st, (uint8_t*)j.d_frame, tbl, (const ResultRec*)d_res, n_max, 1u, (uint32_t*)bad.p);
+            if (n_max < XXH_LANE4_BELOW)
+                hipLaunchKernelGGL((k_xxh32_blocks4<1>), dim3(n_max), dim3(64), 0, st, (uint8_t*)j.d_frame, tbl, (const ResultRec*)d_res, n_max, 1u, (uint32_t*)bad.p);
             else
             hipLaunchKernelGGL((k_xxh32_blocks<W>), dim3((n_max + W - 1) / W), dim3(64 * W), 0, st, (uint8_t*)j.d_frame, tbl,
                                (const ResultRec*)d_res, n_max, 1u, (uint32_t*)bad.p);
@@ -589,7 +589,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
     hipLaunchKernelGGL(k_finish_decode, dim3(1), dim3(64), 0, st, j.d_dst, tbl, (ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size,
                        j.block_checksum ? (const uint32_t*)bad.p : (const uint32_t*)nullptr, plan, ix_flags);
     if (j.content_checksum && !j.d_table && !j.table_in_place && !sw.no_content_check)      // (a whole frame was walked: res->consumed is behind its checksum word)
-        hipLaunchKernelGGL(k_xxh32_content, dim3(1), dim3(256), 0, st, (const uint8_t*)j.d_dst, 0ull, (uint8_t*)j.d_frame, (ResultRec*)d_res, 1u);
+        hipLaunchKernelGGL(k_xxh32_content, dim3(1), dim3(64), 0, st, (const uint8_t*)j.d_dst, 0ull, (uint8_t*)j.d_frame, (ResultRec*)d_res, 1u);
     tick(7, true);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -103,61 +103,88 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_xxh32_blocks(uint8_t* fra
 }
 
 
-// One payload, FOUR waves: XXH32's four accumulators are independent chains until the end, so wave c of a 4-wave workgroup runs
-// accumulator c alone - a quarter of the scalar work per wave, the waves on different SIMDs.  Each wave fetches its own word of
-// every stripe (4 bytes per lane, 16 apart: the same cache lines for all four), two groups of 64 stripes ahead of the chain.
-// Few big payloads (4 MiB blocks: 256 of them per GiB; the content checksum: ONE) get ~4x out of this; many small ones fill
-// the machine with a wave each (wave_xxh32) and gain nothing.  `len` is 64 bits: the content checksum runs over the whole stream
-// (XXH32 adds the length modulo 2^32).  All 256 threads call it; the result is valid in wave 0.
-__device__ __forceinline__ uint32_t wg4_xxh32(const uint8_t* __restrict__ p, uint64_t len, uint32_t* acc4 /* LDS, 4 words */)
+// One payload, one wave, FOUR LANES: XXH32's four accumulators are independent chains until the end, and a wave issues one
+// instruction every ~4.7 cycles whatever it is (tools/probe/chain_rates.hip) - so the chains run as lanes 0..3 of the SAME
+// VALU instructions (v_add, v_alignbit, v_mul_lo: three per 16-byte stripe for all four) instead of one after the other on the
+// scalar unit (twenty).  Operands: the wave fetches 1 KiB per step (16 B per lane, coalesced), multiplies by P2 in all lanes,
+// parks the products in LDS stripe by stripe (four steps in flight), and lane c reads word c of every stripe back with immediate offsets
+// (ds_read_b32, independent of the chain).  Measured 15.7 cycles per stripe against 82 for the scalar form: ~2.4 GB/s per
+// payload.  Few big payloads (4 MiB blocks: 256 per GiB; the content checksum: ONE) are bound by exactly this; many small ones
+// fill the machine with a wave each (wave_xxh32).  `len` is 64 bits: the content checksum runs over the whole stream (XXH32
+// adds the length modulo 2^32).  `park`: 2 KiB of LDS owned by the calling wave (two steps: the next one's products are
+// written while this one's are read).  The result is valid in every lane.
+constexpr uint32_t XXH_PARK = 2048;
+__device__ __forceinline__ uint32_t lane4_xxh32(const uint8_t* __restrict__ p, uint64_t len, uint32_t* park)
 {
-    const uint32_t lane = lane_id(), c = uni(threadIdx.x >> 6) & 3u;
+    const uint32_t lane = lane_id();
     const uint64_t nstripes = len >> 4;
+    uint32_t h = XP5;
     if (len >= 16) {
+        const uint32_t c = lane & 3u;
         uint32_t v = c == 0 ? XP1 + XP2 : c == 1 ? XP2 : c == 2 ? 0u : 0u - XP1;
-        const uint8_t* q = p + 4 * c;
-        auto fetch = [&](uint64_t s0) -> uint32_t {
-            const uint64_t s = s0 + lane;
-            return s < nstripes ? *(const u32_ua*)(q + s * 16) * XP2 : 0u;
+        auto fetch = [&](uint64_t s0) -> b16_ua {                                // (no branch: a stripe beyond the end re-reads the last one and is never used)
+            const uint64_t s = s0 + lane < nstripes ? s0 + lane : nstripes - 1;
+            return *(const b16_ua*)(p + s * 16);
         };
-        uint32_t m = fetch(0), m_next = fetch(WAVE);
-        for (uint64_t s0 = 0; s0 < nstripes; s0 += WAVE) {
-            const uint32_t m_after = fetch(s0 + 2 * WAVE);
+        auto store = [&](const b16_ua& w, uint32_t half) {
+            *(uint4*)((uint8_t*)park + half * 1024u + lane * 16u) = uint4{w.a * XP2, w.b * XP2, w.c * XP2, w.d * XP2};
+        };
+        // four steps of 1 KiB in flight: HBM latency (~2 us) is several chains of 64 (~0.4 us each).  The four registers are
+        // named, not rotated: a rotation is a move, and a move of a register that is still being loaded is a wait for it.
+        // (issued in this order - the barriers keep hipcc from shuffling them - so that "the oldest load" is the same one on
+        // the way into the loop and around it)
+        b16_ua r0 = fetch(0);            asm volatile("" ::: "memory");
+        b16_ua r1 = fetch(WAVE);         asm volatile("" ::: "memory");
+        b16_ua r2 = fetch(2 * WAVE);     asm volatile("" ::: "memory");
+        b16_ua r3 = fetch(3 * WAVE);     asm volatile("" ::: "memory");
+        uint32_t half = 0;
+        auto step = [&](const b16_ua& r, uint64_t s0) {
+            store(r, half);                                                        // (the other half is what the previous step read: in-order LDS)
             const uint32_t n = (nstripes - s0 < WAVE) ? (uint32_t)(nstripes - s0) : WAVE;     // uniform
+            const uint32_t* q = (const uint32_t*)((const uint8_t*)park + half * 1024u) + c;
             if (n == WAVE) {
 #pragma unroll
-                for (int i = 0; i < WAVE; i++) v = rotl32(v + __builtin_amdgcn_readlane(m, i), 13) * XP1;
+                for (int i = 0; i < WAVE; i++) v = rotl32(v + q[i * 4], 13) * XP1;
             } else {
-                for (uint32_t i = 0; i < n; i++) v = rotl32(v + __builtin_amdgcn_readlane(m, i), 13) * XP1;
+                for (uint32_t i = 0; i < n; i++) v = rotl32(v + q[i * 4], 13) * XP1;
             }
-            m = m_next; m_next = m_after;
+            half ^= 1u;
+        };
+        for (uint64_t s0 = 0; s0 < nstripes; s0 += 4 * WAVE) {
+            // (every path issues the same four loads in the same order: the compiler then waits for the oldest one only)
+            step(r0, s0); r0 = fetch(s0 + 4 * WAVE);
+            if (s0 + WAVE < nstripes) step(r1, s0 + WAVE);
+            r1 = fetch(s0 + 5 * WAVE);
+            if (s0 + 2 * WAVE < nstripes) step(r2, s0 + 2 * WAVE);
+            r2 = fetch(s0 + 6 * WAVE);
+            if (s0 + 3 * WAVE < nstripes) step(r3, s0 + 3 * WAVE);
+            r3 = fetch(s0 + 7 * WAVE);
         }
-        if (lane == 0) acc4[c] = v;
+        h = rotl32((uint32_t)__builtin_amdgcn_readlane(v, 0), 1) + rotl32((uint32_t)__builtin_amdgcn_readlane(v, 1), 7) +
+            rotl32((uint32_t)__builtin_amdgcn_readlane(v, 2), 12) + rotl32((uint32_t)__builtin_amdgcn_readlane(v, 3), 18);
     }
-    __syncthreads();
-    uint32_t h = XP5;
-    if (len >= 16) h = rotl32(acc4[0], 1) + rotl32(acc4[1], 7) + rotl32(acc4[2], 12) + rotl32(acc4[3], 18);
     h += (uint32_t)len;
     const uint64_t done = nstripes << 4;
-    h = xxh32_finish(h, p + done, (uint32_t)(len - done));
-    __syncthreads();
-    return h;
+    return xxh32_finish(h, p + done, (uint32_t)(len - done));
 }
 
-constexpr uint32_t XXH_WG_BELOW = 4096;         // fewer blocks than this: a workgroup per block
-// k_xxh32_blocks with a workgroup per block (see wg4_xxh32): the host takes it when there are too few blocks for a wave each
-__global__ __launch_bounds__(256) void k_xxh32_blocks4(uint8_t* frame, BlockOut* __restrict__ table, const ResultRec* __restrict__ res,
-                                                       uint32_t n_max, uint32_t mode, uint32_t* __restrict__ bad)
+constexpr uint32_t XXH_LANE4_BELOW = 16384;     // fewer blocks than this: the four-lane chain (more: a wave each on the scalar unit fills the machine)
+// k_xxh32_blocks with the four-lane chain (lane4_xxh32): the host takes it when there are too few blocks to fill the machine
+// with the scalar form
+template <int WAVES_PER_WG>
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void k_xxh32_blocks4(uint8_t* frame, BlockOut* __restrict__ table, const ResultRec* __restrict__ res,
+                                                                     uint32_t n_max, uint32_t mode, uint32_t* __restrict__ bad)
 {
-    __shared__ uint32_t acc4[4];
-    const uint32_t b = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) uint32_t park[WAVES_PER_WG][XXH_PARK / 4];
+    const uint32_t wv = uni(threadIdx.x >> 6);
+    const uint32_t b = uni(blockIdx.x * WAVES_PER_WG + wv);
     const uint32_t n = res ? res->n_blocks : n_max;
     if (b >= n || b >= n_max) return;
     if (res && res->status != ST_OK) return;
     const uint64_t off = table[b].src_off;
     const uint32_t len = table[b].word & 0x7FFFFFFFu;
-    const uint32_t h = wg4_xxh32(frame + off, len, acc4);
-    if (threadIdx.x == 0) {
+    const uint32_t h = lane4_xxh32(frame + off, len, park[wv]);
+    if (lane_id() == 0) {
         uint8_t* c = frame + off + len;
         if (mode == 0) { c[0] = (uint8_t)h; c[1] = (uint8_t)(h >> 8); c[2] = (uint8_t)(h >> 16); c[3] = (uint8_t)(h >> 24); }
         else {
@@ -168,19 +195,19 @@ __global__ __launch_bounds__(256) void k_xxh32_blocks4(uint8_t* frame, BlockOut*
 }
 
 // The content checksum (Frame format "Content checksum"; LZ4F_compressEnd / LZ4F_decompress at the frame's end): XXH32 of the whole
-// stream, one chain by construction.  One workgroup, ~4x a single wave (measured rate in DESIGN.md) - still seconds per GiB beside a
-// codec that takes milliseconds, so a frame asks for it by its FLG bit and pays for it; the default prefs of the reference's
-// conduit (Conduit.hsc:205) leave it off.
+// stream, one chain by construction.  One wave (lane4_xxh32: ~2.4 GB/s, measured rate in DESIGN.md) - still half a second per GiB
+// beside a codec that takes milliseconds, so a frame asks for it by its FLG bit and pays for it; the default prefs of the
+// reference's conduit (Conduit.hsc:205) leave it off.
 //   mode 0 (compress): `data` is the input; the word goes to the frame's last 4 bytes (res->size counts them already).
 //   mode 1 (decompress): `data` is the decoded output, res->size its length; the stored word is the 4 bytes in front of
 //                        res->consumed; a mismatch sets ERROR_contentChecksum_invalid (18).
-__global__ __launch_bounds__(256) void k_xxh32_content(const uint8_t* __restrict__ data, uint64_t data_len, uint8_t* frame, ResultRec* __restrict__ res, uint32_t mode)
+__global__ __launch_bounds__(64) void k_xxh32_content(const uint8_t* __restrict__ data, uint64_t data_len, uint8_t* frame, ResultRec* __restrict__ res, uint32_t mode)
 {
-    __shared__ uint32_t acc4[4];
+    __shared__ __attribute__((aligned(16))) uint32_t park[XXH_PARK / 4];
     if (res->status != ST_OK) return;
     if (mode == 1 && !((res->flags >> 2) & 1)) return;                 // (the frame has none)
     const uint64_t len = mode == 0 ? data_len : res->size;
-    const uint32_t h = wg4_xxh32(data, len, acc4);
+    const uint32_t h = lane4_xxh32(data, len, park);
     if (threadIdx.x == 0) {
         uint8_t* c = frame + (mode == 0 ? res->size : res->consumed) - 4;
         if (mode == 0) { c[0] = (uint8_t)h; c[1] = (uint8_t)(h >> 8); c[2] = (uint8_t)(h >> 16); c[3] = (uint8_t)(h >> 24); }
