@@ -115,6 +115,205 @@ __device__ __forceinline__ int32_t wave_decode_block(const uint8_t* __restrict__
     }
 }
 
+// ---- independent small blocks: the lanes look for the tokens ----
+// The version above is written for the scalar unit, and that is what a text-like stream (13-byte sequences: 5000 per 64 KiB
+// block, 82 million per GiB) runs out of: a CU has ONE scalar unit, one instruction per cycle for all its waves (a wave gets a
+// turn every ~4.7 cycles, tools/probe/chain_rates.hip), and ~140 scalar instructions per sequence is 20 ms per GiB however
+// many waves there are.  (On top of that every sequence waits for memory three times.)  So here the 64 lanes do the per-
+// sequence work, a window of 64 payload bytes at a time, lane l looking at byte pos + l:
+//   1. every lane reads "its" byte as if it were a token: literal length, match length, and where the next token would be
+//      (lane + 3 + literals) - valid for the common token without length extension bytes that ends inside the window;
+//   2. the scalar unit only hops from token to token (one v_readlane per hop) and collects the mask of real tokens;
+//   3. the real tokens' lanes fetch their offset from the lane it sits in (ds_bpermute), a prefix sum gives every token its
+//      place in the output, a running maximum tells every byte lane which token it belongs to - and ALL literal bytes of the
+//      window go out with one store instruction, each lane its own byte;
+//   4. the matches follow in order, a byte per lane (three v_readlane and a load->store pair per match: the one memory
+//      round trip left per sequence; same-wave accesses are performed in order, so a match sees what was stored before it).
+// Tokens with extension bytes, runs that leave the window, and the block's last ~100 bytes go through `one_sequence`, which
+// is the scalar decoder with the payload in a register window (lane l keeps the 16 bytes at wb + 8*l: token, lengths and
+// offset are four v_readlane and a funnel shift instead of scalar loads; short literal runs come out of the window by
+// ds_bpermute; the next window is on its way while this one is parsed).  Same accept/reject rules as wave_decode_block.
+//   readable: bytes that may be read from `in` on (the frame's end), >= csize
+__device__ __forceinline__ uint32_t dpp_incl_scan_add(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return v;
+}
+__device__ __forceinline__ uint32_t dpp_incl_scan_max(uint32_t v)     // (identity 0)
+{
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;
+    return v;
+}
+
+template <bool VEC>
+__device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable,
+                                                         uint8_t* out, uint32_t cap)
+{
+    if (csize == 0) return -1;
+    const uint32_t lane = lane_id();
+    typedef uint32_t v4u_t __attribute__((ext_vector_type(4)));
+    typedef v4u_t v4u_ua __attribute__((aligned(1)));
+    auto load_win = [&](uint32_t base) -> v4u_t {
+        const uint64_t a = (uint64_t)base + 8u * lane;
+        v4u_t v = {0u, 0u, 0u, 0u};
+        if (a + 16 <= readable) v = *(const v4u_ua*)(in + a);
+        else if (a < readable) {                                             // the frame's last bytes: one by one
+            uint32_t t[4] = {0u, 0u, 0u, 0u};
+            for (uint32_t i = 0; i < 16 && a + i < readable; i++) t[i >> 2] |= (uint32_t)in[a + i] << ((i & 3u) * 8u);
+            v = v4u_t{t[0], t[1], t[2], t[3]};
+        }
+        return v;
+    };
+    v4u_t win = {0u, 0u, 0u, 0u}, nxt = {0u, 0u, 0u, 0u};
+    constexpr uint32_t NONE = 0x80000000u;                                    // (no payload position comes within 504 of it)
+    uint32_t wb = 0u - 512u, nb = NONE;                                      // nothing loaded (a first read near 0 counts as a step over the edge); nb: base of the window in `nxt`, if one is on its way
+    auto ensure = [&](uint32_t qq) {
+        if (qq - wb < 504u) return;                                          // lanes 0..62 serve reads at rel 0..503
+        if (qq - nb < 504u) {                                                // the stream went on where it was: the prefetched window
+            win = nxt; wb = nb;
+            nb = wb + 496u; nxt = load_win(nb);
+        } else {                                                             // a jump (long literal run, or the lanes' path ran ahead): load it now
+            const bool near = qq - wb < 504u + 64u;                          // look ahead again only after a step just over the edge, not a stride
+            wb = qq & ~7u; win = load_win(wb);
+            nb = NONE;
+            if (near) { nb = wb + 496u; nxt = load_win(nb); }
+        }
+    };
+    auto fetch = [&](uint32_t qq) -> uint64_t {                              // 8 payload bytes from qq on
+        ensure(qq);
+        const uint32_t rel = qq - wb, l = rel >> 3, sh8 = (rel & 7u) * 8u;
+        const uint64_t lo = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(win.x, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(win.y, l) << 32);
+        const uint64_t hi = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(win.z, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(win.w, l) << 32);
+        return (lo >> sh8) | ((hi << 1) << (63u - sh8));
+    };
+    auto ext_slow = [&](uint32_t at, uint32_t& after, bool& bad) -> uint32_t {   // length bytes that run on beyond one read
+        uint32_t add = 0;
+        for (;;) {
+            if (at >= csize || add > 0x7FFF0000u) { bad = true; after = at; return add; }
+            const uint32_t b = uni((uint32_t)in[at]);
+            add += b; at++;
+            if (b != 255) { after = at; return add; }
+        }
+    };
+    uint32_t pos = 0, op = 0;
+    // one sequence on the scalar unit.  0: go on, 1: that was the last one, -1: malformed
+    auto one_sequence = [&]() -> int {
+        uint64_t w = fetch(pos);
+        const uint32_t token = (uint32_t)w & 0xFF;
+        uint32_t lit = token >> 4, p = pos + 1;
+        bool bad = false;
+        if (lit == 15) {
+            const uint64_t x = w >> 8;                                       // 7 candidate length bytes, top byte 0 (never 0xFF)
+            const uint32_t f = (uint32_t)__builtin_ctzll(~x), k = f >> 3;
+            lit = 15u + 255u * k + (uint32_t)((x >> (f & 56u)) & 0xFF);
+            p = pos + 2 + k;
+            if (k == 7) lit = 15u + ext_slow(pos + 1, p, bad);
+        }
+        if (bad || p > csize) return -1;
+        const uint32_t in_left = csize - p, out_left = cap - op;
+        const bool is_last = (uint64_t)lit + 12 > out_left || (uint64_t)lit + 8 > in_left;
+        if (is_last && (lit != in_left || lit > out_left)) return -1;
+        if (lit) {
+            const uint32_t rel0 = p - wb;
+            if (lit <= WAVE && rel0 + lit <= 504u) {                         // inside the window: lane i takes byte p + i out of it
+                const uint32_t rel = rel0 + lane, l4 = (rel >> 3) << 2;
+                const uint32_t xa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)l4, (int)win.x), ya = (uint32_t)__builtin_amdgcn_ds_bpermute((int)l4, (int)win.y);
+                const uint32_t word = (rel & 4u) ? ya : xa;
+                if (lane < lit) out[op + lane] = (uint8_t)(word >> ((rel & 3u) * 8u));
+            } else wave_copy_disjoint(out + op, in + p, lit);
+            op += lit;
+        }
+        if (is_last) return 1;
+        const uint32_t qo = p + lit;
+        w = fetch(qo);
+        const uint32_t offset = (uint32_t)w & 0xFFFF;
+        uint32_t mlen = token & 15, npos = qo + 2;
+        if (mlen == 15) {
+            const uint64_t x = w >> 16;                                      // 6 candidate length bytes
+            const uint32_t f = (uint32_t)__builtin_ctzll(~x), k = f >> 3;
+            mlen = 15u + 255u * k + (uint32_t)((x >> (f & 56u)) & 0xFF);
+            npos = qo + 3 + k;
+            if (k == 6) mlen = 15u + ext_slow(qo + 2, npos, bad);
+            if (npos + 4 >= csize) bad = true;
+        }
+        mlen += 4;
+        if (bad || offset == 0 || offset > op || (uint64_t)mlen + 5 > (uint64_t)(cap - op)) return -1;   // (last 5 bytes must be literals)
+        if (mlen <= WAVE) {                                                  // the usual short match: a byte per lane
+            uint32_t idx = lane;
+            if (offset < mlen) idx = lane % offset;                          // (an overlapping one repeats its period)
+            if (lane < mlen) { const uint8_t b = out[op - offset + idx]; out[op + lane] = b; }
+        } else wave_copy_match(out + op, offset, mlen);
+        op += mlen;
+        pos = npos;
+        return 0;
+    };
+    for (;;) {
+        // ---- the lanes' path: a window of 64 payload bytes that starts at a token, away from the block's end ----
+        // (a token here costs >= 3 payload bytes and gives <= 14 + 18 output bytes: a window never makes more than 672; with 96
+        // payload bytes and 1 KiB of room left none of its sequences can be the last one or run into the end-of-block rules)
+        if (VEC && pos <= csize && csize - pos >= 96u && cap - op >= 1024u) {
+            typedef uint32_t u32_ua1 __attribute__((aligned(1)));
+            const uint32_t d = *(const u32_ua1*)(in + pos + lane);
+            const uint32_t t = d & 0xFFu, lit = t >> 4, ml = t & 15u;
+            const bool easy = lit != 15u && ml != 15u && lane + 3u + lit <= 64u;
+            const uint32_t nx = easy ? lane + 3u + lit : 255u;
+            uint64_t mask = 0;
+            uint32_t s = 0;
+            for (;;) {                                                       // the serial part: one hop per token
+                const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)nx, (int)s);
+                if (n > 64u) break;
+                mask |= 1ull << s;
+                s = n;
+                if (s >= 64u) break;
+            }
+            if (mask) {
+                const bool is_tok = (mask >> lane) & 1ull;
+                const uint32_t mlen = ml + 4u;
+                const uint32_t d2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1u + lit) << 2), (int)d);   // the dword of the lane the offset starts in
+                const uint32_t off = d2 & 0xFFFFu;
+                const uint32_t tout = is_tok ? lit + mlen : 0u;
+                const uint32_t incl = dpp_incl_scan_add(tout), ex = incl - tout;
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                const uint32_t mdst = op + ex + lit;                         // where the token's match goes
+                if (__ballot(is_tok && (off == 0u || off > mdst))) return -1;
+                // literals: byte lane l belongs to the nearest token at or below it
+                const uint32_t g1 = dpp_incl_scan_max(is_tok ? lane + 1u : 0u);      // (lane 0 is a token: never 0)
+                const uint32_t pg = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((g1 - 1u) << 2), (int)((ex << 4) | lit));
+                const uint32_t r = lane - g1;                                // byte number within the token's literal run (wraps for the token byte itself)
+                if (lane >= g1 && r < (pg & 15u)) out[op + (pg >> 4) + r] = (uint8_t)d;
+                // matches, in order
+                uint64_t m = mask;
+                while (m) {
+                    const uint32_t k = (uint32_t)__builtin_ctzll(m);
+                    m &= m - 1;
+                    const uint32_t dk = (uint32_t)__builtin_amdgcn_readlane((int)mdst, (int)k), ok = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)k),
+                                   lk = (uint32_t)__builtin_amdgcn_readlane((int)mlen, (int)k);
+                    uint32_t idx = lane;
+                    if (ok < lk) idx = lane % ok;                            // (overlapping: repeats its period; lk <= 18)
+                    if (lane < lk) { const uint8_t b = out[dk - ok + idx]; out[dk + lane] = b; }
+                }
+                op += total;
+                pos += s;
+                continue;
+            }
+        }
+        const int r = one_sequence();
+        if (r < 0) return -1;
+        if (r > 0) return (int32_t)op;
+    }
+}
+
 // Table-driven block decode: wave w of the grid takes block w.
 //   word bit31 set  -> stored block: plain copy
 //   otherwise       -> LZ4 sequences

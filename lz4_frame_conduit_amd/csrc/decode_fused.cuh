@@ -145,6 +145,32 @@ __device__ __forceinline__ void fz_parser(FzShared<C>& sh, const uint8_t* __rest
             if (b != 255) { after = pos; return add; }
         }
     };
+    // The serial part of a sequence is only what the NEXT token's position depends on - the two lengths - and it is written for
+    // the scalar unit, which a wave reaches once every ~4.7 cycles whatever the instruction (tools/probe/chain_rates.hip): every
+    // instruction on the chain is 2 ns per sequence.  So the chain records four numbers per sequence (literal source, literal
+    // length, output position, match length: one v_writelane each) and leaves the rest to `finish_slot`, where the 64 lanes do
+    // it for 64 sequences at once: fetch the offset (2 bytes behind the literals, straight from the payload in L2), apply the
+    // output-side rules, pack the descriptor.  Input-side rules stay on the chain: they are what keeps it inside the payload.
+    uint32_t v_src = 0, v_lit = 0, v_op = 0, v_ml = 0;
+    const uint32_t hist_reach = hist > 65536 ? 65536u : (uint32_t)hist;     // offsets are <= 65535: more history is not distinguishable
+    // rules that need the offset / the output position; returns false if a sequence of the slot breaks one
+    auto finish_slot = [&](uint32_t count) -> bool {
+        uint32_t off = 0;
+        bool bad = false;
+        if (lane < count) {
+            const uint64_t room = (uint64_t)cap - v_op;                          // (op <= cap is kept by the chain)
+            if (v_ml) {
+                const uint8_t* q = in + v_src + v_lit;                           // (the chain checked lit + 8 <= bytes left)
+                off = (uint32_t)q[0] | ((uint32_t)q[1] << 8);
+                bad = off == 0 || off > v_op + v_lit + hist_reach || (uint64_t)v_lit + v_ml + 5 > room;
+            } else bad = v_lit > room;
+        }
+        d0 = v_src | ((off & 0xFFu) << 24);
+        d1 = v_lit | ((off >> 8) << 24);
+        d2 = v_op;
+        d3 = v_ml;
+        return __ballot(bad) == 0;
+    };
     // publish the gathered descriptors as ring slot number `slot_idx`
     auto publish = [&](uint32_t slot_idx) {
         const unsigned long long tr = clock64();
@@ -154,72 +180,73 @@ __device__ __forceinline__ void fz_parser(FzShared<C>& sh, const uint8_t* __rest
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         lds_poke(&sh.produced, slot_idx + 1);
     };
+    // the first 8 bytes of the window lane that holds `qq` (enough for a token; `fetch` gives 8 bytes from qq on)
+    auto fetch_byte = [&](uint32_t qq) -> uint32_t {
+        uint32_t rel = qq - wb;
+        if (rel >= 504u) { reload(qq); rel = qq - wb; }
+        const uint32_t l = rel >> 3, sh8 = (rel & 7u) * 8u;
+        const uint64_t lo = (uint64_t)(uint32_t)__builtin_amdgcn_readlane(win.x, l) | ((uint64_t)(uint32_t)__builtin_amdgcn_readlane(win.y, l) << 32);
+        return (uint32_t)(lo >> sh8) & 0xFFu;
+    };
 
-    // The loop is written for the scalar unit: every quantity is wave-uniform, rule violations are OR-ed into `bad`
-    // and tested once per sequence, and the only branches on the usual path are "window miss", "last sequence" and
-    // "slot full".  (Early exits in the middle of the body cost more in control-flow bookkeeping than the work itself.)
     uint32_t pos = 0;
     uint32_t fin = status;                                                  // bit 0 error, bit 1 last sequence done
-    const uint32_t hist_reach = hist > 65536 ? 65536u : (uint32_t)hist;     // offsets are <= 65535: more history is not distinguishable
     while (fin == 0) {
         // ---- token, literal length ----
-        const uint64_t w = fetch(pos);
-        const uint32_t token = (uint32_t)w & 0xFF;
+        const uint32_t token = fetch_byte(pos);
         uint32_t lit = token >> 4;
         uint32_t p = pos + 1;                                                // first literal byte
         uint32_t bad = 0;
-        {
-            const uint64_t x = w >> 8;                                       // 7 candidate length bytes, top byte 0 (never 0xFF)
+        if (lit == 15) {
+            const uint64_t x = fetch(pos) >> 8;                              // 7 candidate length bytes, top byte 0 (never 0xFF)
             const uint32_t f = (uint32_t)__builtin_ctzll(~x);
             const uint32_t k = f >> 3;
-            const uint32_t ext = 255u * k + (uint32_t)((x >> (f & 56u)) & 0xFF);
-            const bool is15 = lit == 15;
-            lit = is15 ? 15u + ext : lit;
-            p = is15 ? pos + 2 + k : p;
-            if (is15 && k == 7) { lit = 15u + ext_slow(pos + 1, p); bad |= status; }
+            lit = 15u + 255u * k + (uint32_t)((x >> (f & 56u)) & 0xFF);
+            p = pos + 2 + k;
+            if (k == 7) { lit = 15u + ext_slow(pos + 1, p); bad |= status; }
         }
         bad |= p > csize ? 1u : 0u;
         const uint32_t in_left = csize - p;
-        const uint32_t lit_src = p;
         const bool is_last = lit > in_left || lit + 8 > in_left || lit + 12 > cap - op;   // lit < 2^31
-        uint32_t mlen = 0, off = 0, npos = pos;
+        uint32_t mlen = 0, npos = pos;
         if (!is_last) {
-            // ---- offset, match length ----
+            // ---- match length (the offset itself is finish_slot's) ----
             const uint32_t qo = p + lit;
-            const uint64_t w2 = fetch(qo);
-            off = (uint32_t)w2 & 0xFFFF;
-            bad |= off == 0 ? 1u : 0u;
-            bad |= off > op + lit + hist_reach ? 1u : 0u;
-            const uint64_t x = w2 >> 16;                                     // 6 candidate length bytes
-            const uint32_t f = (uint32_t)__builtin_ctzll(~x);
-            const uint32_t k = f >> 3;
-            const uint32_t ext = 255u * k + (uint32_t)((x >> (f & 56u)) & 0xFF);
-            const bool is15 = (token & 15) == 15;
-            mlen = is15 ? 15u + ext : (token & 15);
-            npos = is15 ? qo + 3 + k : qo + 2;
-            if (is15 && k == 6) { mlen = 15u + ext_slow(qo + 2, npos); bad |= status; }
-            bad |= (is15 && npos + 4 >= csize) ? 1u : 0u;
+            mlen = token & 15;
+            npos = qo + 2;
+            if (mlen == 15) {
+                const uint64_t x = fetch(qo) >> 16;                          // 6 candidate length bytes
+                const uint32_t f = (uint32_t)__builtin_ctzll(~x);
+                const uint32_t k = f >> 3;
+                mlen = 15u + 255u * k + (uint32_t)((x >> (f & 56u)) & 0xFF);
+                npos = qo + 3 + k;
+                if (k == 6) { mlen = 15u + ext_slow(qo + 2, npos); bad |= status; }
+                bad |= npos + 4 >= csize ? 1u : 0u;
+            }
             mlen += 4;
-            bad |= mlen + 5 > cap - (op + lit) ? 1u : 0u;
+            bad |= mlen > cap - (op + lit) ? 1u : 0u;                         // (keeps op <= cap; the exact rule is finish_slot's)
         } else {
             bad |= lit != in_left ? 1u : 0u;
             bad |= lit > cap - op ? 1u : 0u;
         }
         fin |= bad;
-        if (fin == 0) {                                                      // a good sequence: record it
+        if (fin == 0) {                                                      // record it
             const uint32_t slot = nseq & 63;
-            const bool mine = lane == slot;                                  // select, not branch: the loop stays scalar
-            d0 = mine ? (lit_src | ((off & 0xFFu) << 24)) : d0;
-            d1 = mine ? (lit | ((off >> 8) << 24)) : d1;
-            d2 = mine ? op : d2;
-            d3 = mine ? mlen : d3;
+            // (gfx9: one scalar operand per VALU instruction, so the lane number travels in M0 - which is the compiler's, hence kept)
+            uint32_t keep;
+            asm("s_mov_b32 %4, m0\n\ts_mov_b32 m0, %5\n\tv_writelane_b32 %0, %6, m0\n\tv_writelane_b32 %1, %7, m0\n\tv_writelane_b32 %2, %8, m0\n\tv_writelane_b32 %3, %9, m0\n\ts_mov_b32 m0, %4"
+                : "+v"(v_src), "+v"(v_lit), "+v"(v_op), "+v"(v_ml), "=&s"(keep) : "s"(slot), "s"(p), "s"(lit), "s"(op), "s"(mlen));
             nseq++;
             op += lit + mlen;
-            if (slot == 63) publish((nseq >> 6) - 1);
+            if (slot == 63) {
+                if (finish_slot(64)) publish((nseq >> 6) - 1);
+                else { fin |= 1u; nseq -= 64; }                               // (nothing of a slot with a bad sequence is published)
+            }
             pos = npos;
             fin |= is_last ? 2u : (pos >= csize ? 1u : 0u);
         }
     }
+    if ((fin & 1u) == 0 && (nseq & 63) && !finish_slot(nseq & 63)) fin |= 1u;    // the partial last slot
     if (fin & 1u) status = 1;
     // final bookkeeping.  Order matters for the partial last slot: its size must be readable by whoever sees it
     // published, so totals and `finished` are written BEFORE `produced` is bumped for it (LDS ops of one wave are

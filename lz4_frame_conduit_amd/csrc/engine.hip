@@ -581,7 +581,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         } else {
             plan |= LZ4F_MI355X_PATH_WAVE_PER_BLOCK;
             hipLaunchKernelGGL((k_decode_blocks<W>), dim3(grid), dim3(64 * W), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl, (const ResultRec*)d_res,
-                               n_max, j.linked ? 1u : 0u, j.block_size, j.hist0);
+                               n_max, j.linked ? 1u : 0u, j.block_size, j.hist0, (uint64_t)j.frame_cap);
         }
         tick(6, true);
     }

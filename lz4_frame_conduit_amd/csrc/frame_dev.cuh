@@ -602,7 +602,8 @@ __global__ void k_set_block(BlockOut* t, BlockOut e) { if (threadIdx.x == 0 && b
 template <int WAVES_PER_WG>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_decode_blocks(const uint8_t* __restrict__ frame, uint8_t* dst, uint64_t dst_cap,
                                                                      BlockOut* __restrict__ table, const ResultRec* __restrict__ res,
-                                                                     uint32_t n_max, uint32_t linked, uint32_t block_size, uint64_t hist0)
+                                                                     uint32_t n_max, uint32_t linked, uint32_t block_size, uint64_t hist0,
+                                                                     uint64_t frame_cap)
 {
     const uint32_t w = uni(blockIdx.x * WAVES_PER_WG + (threadIdx.x >> 6));
     if (res->status != ST_OK) return;
@@ -617,7 +618,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_decode_blocks(const uint8
             if (csz > e.dst_size) got = -2;
             else { wave_copy_disjoint(dst + e.dst_off, frame + e.src_off, csz); got = (int32_t)csz; }
         } else {
-            got = wave_decode_block(frame + e.src_off, csz, dst + e.dst_off, e.dst_size, 0);
+            got = wave_decode_block_win<true>(frame + e.src_off, csz, frame_cap - e.src_off, dst + e.dst_off, e.dst_size);
         }
         if (lane == 0) table[w].dst_size = (uint32_t)got;            // negative = failed
         return;

@@ -7,7 +7,8 @@ import torch
 from lz4_frame_conduit_amd import _ffi, conduit
 from lz4_frame_conduit_amd.device import Engine, synth50_device
 n = (int(sys.argv[1]) if len(sys.argv) > 1 else 4096) << 20
-src = synth50_device(n, 1234); eng = Engine(0)
+from lz4_frame_conduit_amd import datagen
+src = torch.from_numpy(datagen.synth_text(n, 5)).cuda() if "text" in sys.argv else synth50_device(n, 1234); eng = Engine(0)
 p = conduit.make_preferences(blockSizeID=7, blockMode=1)
 frame = torch.empty(eng.frame_bound(n, p), dtype=torch.uint8, device="cuda"); nb = n >> 22; table = eng.new_table(nb)
 index = eng.new_index(n, p) if len(sys.argv) > 2 and sys.argv[2] == "ix" else None
