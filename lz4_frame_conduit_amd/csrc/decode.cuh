@@ -158,7 +158,7 @@ __device__ __forceinline__ uint32_t dpp_incl_scan_max(uint32_t v)     // (identi
 
 template <bool VEC>
 __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable,
-                                                         uint8_t* out, uint32_t cap)
+                                                         uint8_t* out, uint32_t cap, uint32_t* expand /* 64 words of LDS, this wave's */)
 {
     if (csize == 0) return -1;
     const uint32_t lane = lane_id();
@@ -292,8 +292,27 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
                 const uint32_t pg = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((g1 - 1u) << 2), (int)((ex << 4) | lit));
                 const uint32_t r = lane - g1;                                // byte number within the token's literal run (wraps for the token byte itself)
                 if (lane >= g1 && r < (pg & 15u)) out[op + (pg >> 4) + r] = (uint8_t)d;
-                // matches, in order
-                uint64_t m = mask;
+                // matches.  Most of them read what earlier windows wrote: those go together, lane j taking byte j of the window's
+                // match bytes (the first 64 of them) - a prefix sum places every match in that space, its lane leaves its number
+                // at the start of its run (`expand`, 64 words of LDS), a running maximum spreads it over the run.  A match whose
+                // source reaches into this window's own matches (or that lies beyond byte 64) waits for the ordered loop behind.
+                const uint32_t mcnt = is_tok ? mlen : 0u;
+                const uint32_t mincl = dpp_incl_scan_add(mcnt), mex = mincl - mcnt;
+                const uint32_t md0 = (uint32_t)__builtin_amdgcn_readlane((int)mdst, 0);          // the window's first match: everything in front of it is stored or on its way
+                const bool together = is_tok && mincl <= WAVE && mdst - off + mlen <= md0 ;
+                // (the first token always qualifies: its source ends in front of its own destination = md0 only if off >= mlen)
+                // (volatile: to the compiler a lane that stores nothing in between reads back its own 0 - the other lanes' stores
+                // are not in its picture; same-wave LDS accesses are performed in order, so nothing else is needed)
+                volatile uint32_t* const xp = expand;
+                xp[lane] = 0u;
+                if (together) xp[mex] = lane + 1u;
+                const uint32_t k1 = dpp_incl_scan_max(xp[lane]);                               // 0: no match of the batch covers byte j
+                const uint32_t kk = ((k1 ? k1 : 1u) - 1u) << 2;
+                const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)kk, (int)(mdst | (mlen << 20))),
+                               pb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)kk, (int)(off | (mex << 16)));
+                const uint32_t bi = lane - (pb >> 16), bd = pa & 0xFFFFFu;                     // my byte within the match, the match's destination
+                if (k1 && bi < (pa >> 20)) { const uint8_t b = out[bd - (pb & 0xFFFFu) + bi]; out[bd + bi] = b; }
+                uint64_t m = __ballot(is_tok && !together);                                    // the others, in order
                 while (m) {
                     const uint32_t k = (uint32_t)__builtin_ctzll(m);
                     m &= m - 1;

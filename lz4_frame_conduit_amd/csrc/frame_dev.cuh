@@ -605,6 +605,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_decode_blocks(const uint8
                                                                      uint32_t n_max, uint32_t linked, uint32_t block_size, uint64_t hist0,
                                                                      uint64_t frame_cap)
 {
+    __shared__ uint32_t expand[WAVES_PER_WG][64];
     const uint32_t w = uni(blockIdx.x * WAVES_PER_WG + (threadIdx.x >> 6));
     if (res->status != ST_OK) return;
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
@@ -618,7 +619,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_decode_blocks(const uint8
             if (csz > e.dst_size) got = -2;
             else { wave_copy_disjoint(dst + e.dst_off, frame + e.src_off, csz); got = (int32_t)csz; }
         } else {
-            got = wave_decode_block_win<true>(frame + e.src_off, csz, frame_cap - e.src_off, dst + e.dst_off, e.dst_size);
+            got = wave_decode_block_win<true>(frame + e.src_off, csz, frame_cap - e.src_off, dst + e.dst_off, e.dst_size, expand[uni(threadIdx.x >> 6)]);
         }
         if (lane == 0) table[w].dst_size = (uint32_t)got;            // negative = failed
         return;
