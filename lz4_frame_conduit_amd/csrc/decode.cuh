@@ -292,26 +292,34 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
                 const uint32_t pg = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((g1 - 1u) << 2), (int)((ex << 4) | lit));
                 const uint32_t r = lane - g1;                                // byte number within the token's literal run (wraps for the token byte itself)
                 if (lane >= g1 && r < (pg & 15u)) out[op + (pg >> 4) + r] = (uint8_t)d;
-                // matches.  Most of them read what earlier windows wrote: those go together, lane j taking byte j of the window's
-                // match bytes (the first 64 of them) - a prefix sum places every match in that space, its lane leaves its number
-                // at the start of its run (`expand`, 64 words of LDS), a running maximum spreads it over the run.  A match whose
-                // source reaches into this window's own matches (or that lies beyond byte 64) waits for the ordered loop behind.
+                // matches.  Most of them read what earlier windows wrote: those go together, 64 match bytes of the window per round, a
+                // lane per byte - a prefix sum places every match in that space, its lane leaves its number at the start of its run
+                // (`expand`, 64 words of LDS), a running maximum spreads it over the run.  A match whose source reaches into this
+                // window's own matches waits for the ordered loop behind.
                 const uint32_t mcnt = is_tok ? mlen : 0u;
                 const uint32_t mincl = dpp_incl_scan_add(mcnt), mex = mincl - mcnt;
+                const uint32_t mtotal = (uint32_t)__builtin_amdgcn_readlane((int)mincl, 63);
                 const uint32_t md0 = (uint32_t)__builtin_amdgcn_readlane((int)mdst, 0);          // the window's first match: everything in front of it is stored or on its way
-                const bool together = is_tok && mincl <= WAVE && mdst - off + mlen <= md0 ;
-                // (the first token always qualifies: its source ends in front of its own destination = md0 only if off >= mlen)
-                // (volatile: to the compiler a lane that stores nothing in between reads back its own 0 - the other lanes' stores
-                // are not in its picture; same-wave LDS accesses are performed in order, so nothing else is needed)
-                volatile uint32_t* const xp = expand;
-                xp[lane] = 0u;
-                if (together) xp[mex] = lane + 1u;
-                const uint32_t k1 = dpp_incl_scan_max(xp[lane]);                               // 0: no match of the batch covers byte j
-                const uint32_t kk = ((k1 ? k1 : 1u) - 1u) << 2;
-                const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)kk, (int)(mdst | (mlen << 20))),
-                               pb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)kk, (int)(off | (mex << 16)));
-                const uint32_t bi = lane - (pb >> 16), bd = pa & 0xFFFFFu;                     // my byte within the match, the match's destination
-                if (k1 && bi < (pa >> 20)) { const uint8_t b = out[bd - (pb & 0xFFFFu) + bi]; out[bd + bi] = b; }
+                const bool indep = is_tok && mdst - off + mlen <= md0;                          // (implies off >= mlen: no overlap with itself either)
+                const uint32_t pa_mine = mdst | (mlen << 20);
+                volatile uint32_t* const xp = expand;                         // (volatile: see below)
+                for (uint32_t base = 0; base < mtotal;) {                     // rounds of up to 64 match bytes, cut between matches
+                    const bool fits = is_tok && mex >= base && mincl <= base + WAVE;
+                    const uint64_t fm = __ballot(fits);                      // (never empty: a match here is at most 18 bytes)
+                    const uint32_t nbase = (uint32_t)__builtin_amdgcn_readlane((int)mincl, 63 - (int)__builtin_clzll(fm));
+                    // to the compiler a lane that stores nothing in between reads back its own 0 - the other lanes' stores are not
+                    // in its picture, hence volatile; same-wave LDS accesses are performed in order, so nothing else is needed
+                    xp[lane] = 0u;
+                    if (fits && indep) xp[mex - base] = lane + 1u;
+                    const uint32_t k1 = dpp_incl_scan_max(xp[lane]);                           // 0: no match of the round covers byte j
+                    const uint32_t kk = ((k1 ? k1 : 1u) - 1u) << 2;
+                    const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)kk, (int)pa_mine),
+                                   pb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)kk, (int)(off | ((mex - base) << 16)));
+                    const uint32_t bi = lane - (pb >> 16), bd = pa & 0xFFFFFu;                 // my byte within the match, the match's destination
+                    if (k1 && bi < (pa >> 20)) { const uint8_t b = out[bd - (pb & 0xFFFFu) + bi]; out[bd + bi] = b; }
+                    base = nbase;
+                }
+                const bool together = indep;
                 uint64_t m = __ballot(is_tok && !together);                                    // the others, in order
                 while (m) {
                     const uint32_t k = (uint32_t)__builtin_ctzll(m);
