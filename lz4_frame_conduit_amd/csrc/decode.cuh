@@ -268,22 +268,25 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
             const uint32_t t = d & 0xFFu, lit = t >> 4, ml = t & 15u;
             const bool easy = lit != 15u && ml != 15u && lane + 3u + lit <= 64u;
             const uint32_t nx = easy ? lane + 3u + lit : 255u;
+            // the serial part: one hop per token (v_readlane, s_bitset1, two moves, compare, branch).  A token is marked before its
+            // end is known; the last one is taken back if it does not end inside the window.
             uint64_t mask = 0;
-            uint32_t s = 0;
-            for (;;) {                                                       // the serial part: one hop per token
-                const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)nx, (int)s);
-                if (n > 64u) break;
-                mask |= 1ull << s;
-                s = n;
-                if (s >= 64u) break;
-            }
+            uint32_t s = 0, sp = 0, n;
+            do {
+                n = (uint32_t)__builtin_amdgcn_readlane((int)nx, (int)s);
+                asm("s_bitset1_b64 %0, %1" : "+s"(mask) : "s"(s));
+                sp = s; s = n;
+            } while (n < 64u);
+            if (n > 64u) { mask &= ~(1ull << sp); s = sp; }
             if (mask) {
                 const bool is_tok = (mask >> lane) & 1ull;
                 const uint32_t mlen = ml + 4u;
                 const uint32_t d2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1u + lit) << 2), (int)d);   // the dword of the lane the offset starts in
                 const uint32_t off = d2 & 0xFFFFu;
-                const uint32_t tout = is_tok ? lit + mlen : 0u;
-                const uint32_t incl = dpp_incl_scan_add(tout), ex = incl - tout;
+                // one prefix sum for two spaces: the window's output bytes (low half) and its match bytes (high half; <= 672 and 378)
+                const uint32_t tout = is_tok ? lit + mlen : 0u, mcnt = is_tok ? mlen : 0u;
+                const uint32_t both = dpp_incl_scan_add(tout | (mcnt << 16));
+                const uint32_t incl = both & 0xFFFFu, ex = incl - tout, mincl = both >> 16, mex = mincl - mcnt;
                 const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                 const uint32_t mdst = op + ex + lit;                         // where the token's match goes
                 if (__ballot(is_tok && (off == 0u || off > mdst))) return -1;
@@ -296,8 +299,6 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
                 // lane per byte - a prefix sum places every match in that space, its lane leaves its number at the start of its run
                 // (`expand`, 64 words of LDS), a running maximum spreads it over the run.  A match whose source reaches into this
                 // window's own matches waits for the ordered loop behind.
-                const uint32_t mcnt = is_tok ? mlen : 0u;
-                const uint32_t mincl = dpp_incl_scan_add(mcnt), mex = mincl - mcnt;
                 const uint32_t mtotal = (uint32_t)__builtin_amdgcn_readlane((int)mincl, 63);
                 const uint32_t md0 = (uint32_t)__builtin_amdgcn_readlane((int)mdst, 0);          // the window's first match: everything in front of it is stored or on its way
                 const bool indep = is_tok && mdst - off + mlen <= md0;                          // (implies off >= mlen: no overlap with itself either)
