@@ -207,6 +207,7 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
         }
     };
     uint32_t pos = 0, op = 0;
+    uint32_t dnext = 0, dnext_pos = NONE;                                    // the lanes' path: the next window's bytes, asked for ahead of time
     // one sequence on the scalar unit.  0: go on, 1: that was the last one, -1: malformed
     auto one_sequence = [&]() -> int {
         uint64_t w = fetch(pos);
@@ -264,7 +265,7 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
         // payload bytes and 1 KiB of room left none of its sequences can be the last one or run into the end-of-block rules)
         if (VEC && pos <= csize && csize - pos >= 96u && cap - op >= 1024u) {
             typedef uint32_t u32_ua1 __attribute__((aligned(1)));
-            const uint32_t d = *(const u32_ua1*)(in + pos + lane);
+            const uint32_t d = dnext_pos == pos ? dnext : *(const u32_ua1*)(in + pos + lane);
             const uint32_t t = d & 0xFFu, lit = t >> 4, ml = t & 15u;
             const bool easy = lit != 15u && ml != 15u && lane + 3u + lit <= 64u;
             const uint32_t nx = easy ? lane + 3u + lit : 255u;
@@ -279,6 +280,11 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
             } while (n < 64u);
             if (n > 64u) { mask &= ~(1ull << sp); s = sp; }
             if (mask) {
+                // the next window's bytes are asked for as soon as it is known where it starts: they travel while this window's
+                // literals and matches are stored (memory operations of a wave return in order: by the time a match's bytes are
+                // there, so are these)
+                dnext_pos = pos + s;
+                if (csize - dnext_pos >= 96u) dnext = *(const u32_ua1*)(in + dnext_pos + lane); else dnext_pos = NONE;
                 const bool is_tok = (mask >> lane) & 1ull;
                 const uint32_t mlen = ml + 4u;
                 const uint32_t d2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1u + lit) << 2), (int)d);   // the dword of the lane the offset starts in

@@ -600,7 +600,7 @@ __global__ void k_set_block(BlockOut* t, BlockOut e) { if (threadIdx.x == 0 && b
 
 // `hist0`: valid bytes directly in front of dst (streaming API: the previous blocks' last 64 KiB).
 template <int WAVES_PER_WG>
-__global__ __launch_bounds__(64 * WAVES_PER_WG) void k_decode_blocks(const uint8_t* __restrict__ frame, uint8_t* dst, uint64_t dst_cap,
+__global__ __launch_bounds__(64 * WAVES_PER_WG, 8) void k_decode_blocks(const uint8_t* __restrict__ frame, uint8_t* dst, uint64_t dst_cap,
                                                                      BlockOut* __restrict__ table, const ResultRec* __restrict__ res,
                                                                      uint32_t n_max, uint32_t linked, uint32_t block_size, uint64_t hist0,
                                                                      uint64_t frame_cap)
