@@ -286,7 +286,7 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
         if (j.block_checksum) {
             tick(3, false);
             if (g.n_blocks < XXH_LANE4_BELOW)                          // few big blocks: the four accumulators as four lanes (lane4_xxh32)
-                hipLaunchKernelGGL((k_xxh32_blocks4<1>), dim3(g.n_blocks), dim3(64), 0, st, d_dst, (BlockOut*)d_table, (const ResultRec*)d_res, g.n_blocks, 0u, (uint32_t*)nullptr);
+                hipLaunchKernelGGL((k_xxh32_blocks4<1>), dim3(g.n_blocks), dim3(64), XXH_SPREAD_LDS, st, d_dst, (BlockOut*)d_table, (const ResultRec*)d_res, g.n_blocks, 0u, (uint32_t*)nullptr);
             else
             hipLaunchKernelGGL((k_xxh32_blocks<W>), dim3((g.n_blocks + W - 1) / W), dim3(64 * W), 0, st, d_dst, (BlockOut*)d_table,
                                (const ResultRec*)d_res, g.n_blocks, 0u, (uint32_t*)nullptr);
@@ -377,7 +377,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         if (j.block_checksum) {
             tick(5, false);
             if (n_max < XXH_LANE4_BELOW)
-                hipLaunchKernelGGL((k_xxh32_blocks4<1>), dim3(n_max), dim3(64), 0, st, (uint8_t*)j.d_frame, tbl, (const ResultRec*)d_res, n_max, 1u, (uint32_t*)bad.p);
+                hipLaunchKernelGGL((k_xxh32_blocks4<1>), dim3(n_max), dim3(64), XXH_SPREAD_LDS, st, (uint8_t*)j.d_frame, tbl, (const ResultRec*)d_res, n_max, 1u, (uint32_t*)bad.p);
             else
             hipLaunchKernelGGL((k_xxh32_blocks<W>), dim3((n_max + W - 1) / W), dim3(64 * W), 0, st, (uint8_t*)j.d_frame, tbl,
                                (const ResultRec*)d_res, n_max, 1u, (uint32_t*)bad.p);

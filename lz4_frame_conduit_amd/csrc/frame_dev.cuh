@@ -168,6 +168,9 @@ __device__ __forceinline__ uint32_t lane4_xxh32(const uint8_t* __restrict__ p, u
     return xxh32_finish(h, p + done, (uint32_t)(len - done));
 }
 
+// (asked for as dynamic LDS and never touched: at most four of these one-wave workgroups per CU, so each chain has a SIMD's issue
+// slots to itself - the dispatcher otherwise stacks several on one SIMD while others idle, and the chain is issue-bound)
+constexpr uint32_t XXH_SPREAD_LDS = 36u << 10;
 constexpr uint32_t XXH_LANE4_BELOW = 16384;     // fewer blocks than this: the four-lane chain (more: a wave each on the scalar unit fills the machine)
 // k_xxh32_blocks with the four-lane chain (lane4_xxh32): the host takes it when there are too few blocks to fill the machine
 // with the scalar form
