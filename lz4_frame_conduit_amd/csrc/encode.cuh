@@ -467,32 +467,42 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                     const uint32_t hvB = e1_mix(vB), hB = e1_slot(hvB), tgB = e1_tag(hvB);
                     const uint32_t eA = sh.table[hA], etA = sh.tags[hA], eB = sh.table[hB], etB = sh.tags[hB];
                     const uint32_t distA = (pA - eA) & 0xFFFFu, distB = (pB - eB) & 0xFFFFu;
-                    // 21 hash bits agree: worth a look at the bytes (in incompressible input one step in five gets that far)
-                    const bool okA = actA && etA == tgA && distA != 0 && distA <= pA - low;
-                    const bool okB = actB && etB == tgB && distB != 0 && distB <= pB - low;
+                    // 21 hash bits agree: worth a look at the bytes (in incompressible input one step in five gets that far).
+                    // Written so that each question is ONE vector compare whose result IS the ballot: tag difference, distance range and
+                    // "is this lane probing at all" folded into x < limit.  (As a chain of && hipcc makes an exec-mask block per term -
+                    // save, branch, restore on the scalar unit, which the 16 waves of the workgroup share and this loop runs out of.)
+                    const uint32_t roomA = pA - low, roomB = pB - low;                                   // (a distance is < 2^16 anyway: the cap keeps the marker bits above any limit)
+                    const uint32_t limA = actA ? (roomA < 65536u ? roomA : 65536u) : 0u, limB = actB ? (roomB < 65536u ? roomB : 65536u) : 0u;
+                    const uint32_t xA = ((distA - 1u) & 0xFFFFu) | ((etA ^ tgA) << 20) | (distA == 0u ? 1u << 19 : 0u);
+                    const uint32_t xB = ((distB - 1u) & 0xFFFFu) | ((etB ^ tgB) << 20) | (distB == 0u ? 1u << 19 : 0u);
                     // The table is shared with waves further ahead, and a run of one byte (or of a short period) is a single hot slot that
                     // always holds a position of whoever is furthest ahead.  Such runs are found without it: the lane below probes the
                     // position `step` bytes back, and if its four bytes are mine, that is a match.
                     const uint32_t nbA = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vA, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
                     const uint32_t nbB = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vB, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
-                    uint64_t m = __ballot(okA);
-                    if (m) m = __ballot(okA && e1_ld32(sh.ring, pA - distA) == vA);
-                    uint64_t mr = __ballot(actA && (lane & 15u) != 0 && nbA == vA) & ~m;
+                    const uint32_t row0 = (lane & 15u) == 0u ? 1u : 0u;
+                    uint64_t m = __ballot(xA < limA);
+                    if (m) m &= __ballot(e1_ld32(sh.ring, pA - distA) == vA);                    // (every lane looks: harmless, the ring is a power of two)
+                    uint64_t mr = __ballot(((nbA ^ vA) | row0 | (actA ? 0u : 1u)) == 0u) & ~m;
                     m |= mr;
                     bool inB = false;
                     if (!m) {
-                        if (actA) { sh.table[hA] = (uint16_t)pA; sh.tags[hA] = (uint8_t)tgA; }
-                        m = __ballot(okB);
-                        if (m) m = __ballot(okB && e1_ld32(sh.ring, pB - distB) == vB);
-                        mr = __ballot(actB && (lane & 15u) != 0 && nbB == vB) & ~m;
+                        // (lanes that have nothing to insert store to a word of their own: a select on the address instead of an exec-mask block)
+                        *(actA ? &sh.table[hA] : (uint16_t*)&sh.idle[lane]) = (uint16_t)pA; *(actA ? &sh.tags[hA] : (uint8_t*)&sh.idle[lane]) = (uint8_t)tgA;
+                        m = __ballot(xB < limB);
+                        if (m) m &= __ballot(e1_ld32(sh.ring, pB - distB) == vB);
+                        mr = __ballot(((nbB ^ vB) | row0 | (actB ? 0u : 1u)) == 0u) & ~m;
                         m |= mr;
                         inB = true;
                     }
                     // the greedy parse indexes the positions up to the match it takes, not the ones it jumps over: those come up
                     // again in the next step and would find themselves in the table instead of their candidates
                     const uint32_t L = m ? (uint32_t)__builtin_ctzll(m) : WAVE;
-                    if (!inB) { if (actA && lane <= L) { sh.table[hA] = (uint16_t)pA; sh.tags[hA] = (uint8_t)tgA; } }
-                    else      { if (actB && lane <= L) { sh.table[hB] = (uint16_t)pB; sh.tags[hB] = (uint8_t)tgB; } }
+                    {
+                        const bool ins = (inB ? actB : actA) && lane <= L;
+                        const uint32_t hI = inB ? hB : hA, pI = inB ? pB : pA, tI = inB ? tgB : tgA;
+                        *(ins ? &sh.table[hI] : (uint16_t*)&sh.idle[lane]) = (uint16_t)pI; *(ins ? &sh.tags[hI] : (uint8_t*)&sh.idle[lane]) = (uint8_t)tI;
+                    }
                     E1DBG(const unsigned long long z2 = clock64(); a_probe += z2 - z1;)
                     if (!m) { ip = two ? ipB + WAVE * stepB : ipB; step += 1 + two; two = 1; continue; }
                     E1DBG(n_hit++;)
