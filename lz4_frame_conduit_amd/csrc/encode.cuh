@@ -127,7 +127,10 @@ static_assert(64 * E1_WAVES >= E1_NSLICE, "a thread per slice when the lists are
 #ifndef E1_GRAB
 #define E1_GRAB 8
 #endif
-constexpr uint32_t E1_GRAB_SPARSE = E1_GRAB, E1_PROBE_SLICES = 16, E1_DENSE_HITS = 24;
+#ifndef E1_GRAB_D
+#define E1_GRAB_D 1
+#endif
+constexpr uint32_t E1_GRAB_SPARSE = E1_GRAB, E1_GRAB_DENSE = E1_GRAB_D, E1_PROBE_SLICES = 16, E1_DENSE_HITS = 24;
 
 // 4 / 8 bytes at any byte position of the ring.  (A byte-unaligned ds_read_b32 / _b64 is legal on gfx950 but keeps the LDS busy
 // for ~20 cycles per wave instruction - measured: SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS - so the reads are dword-aligned and the
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
             // table slot per distinct four bytes, always holding a position of whoever is furthest ahead - that slice finds it,
             // publishes its end, and nobody searches what it covers.
             const bool opener = fresh && wave == 0;
-            const uint32_t grab = (mode == 1 && !opener) ? E1_GRAB_SPARSE : 1u;
+            const uint32_t grab = opener ? 1u : mode == 1 ? E1_GRAB_SPARSE : mode == 2 ? E1_GRAB_DENSE : 1u;
             uint32_t si = 0;
             if (!opener) {
                 if (fresh) for (uint32_t spin = 0; spin < 4096 && uni(__hip_atomic_load(&sh.first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0; spin++) __builtin_amdgcn_s_sleep(2);
