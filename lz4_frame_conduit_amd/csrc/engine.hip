@@ -369,7 +369,8 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         hipLaunchKernelGGL(k_walk_frame, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, j.dst_cap, tbl, n_max, (ResultRec*)d_res, walked);
         tick(4, true);
     }
-    HIP_TRY(hipMemsetAsync(bad.p, 0xFF, 4, st));
+    HIP_TRY(hipMemsetAsync(bad.p, 0xFF, 8, st));                     // [0] block-checksum verdict, [1] first failed block
+    HIP_TRY(hipMemsetAsync((uint8_t*)bad.p + 8, 0, 24, st));        // [2] "something has to move", [4..5] sum of sizes (k_finish_check)
     constexpr int W = 4;
     const uint32_t grid = j.linked ? 1u : (n_max + W - 1) / W;
     const uint32_t* ix_flags = nullptr;                              // the indexed kernels' "gave up" word, if they were launched
@@ -586,8 +587,9 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         tick(6, true);
     }
     tick(7, false);
+    if (n_max) hipLaunchKernelGGL(k_finish_check, dim3((n_max + 255) / 256), dim3(256), 0, st, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, (uint32_t*)bad.p);
     hipLaunchKernelGGL(k_finish_decode, dim3(1), dim3(64), 0, st, j.d_dst, tbl, (ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size,
-                       j.block_checksum ? (const uint32_t*)bad.p : (const uint32_t*)nullptr, plan, ix_flags);
+                       (const uint32_t*)bad.p, j.block_checksum ? 1u : 0u, plan, ix_flags);
     if (j.content_checksum && !j.d_table && !j.table_in_place && !sw.no_content_check)      // (a whole frame was walked: res->consumed is behind its checksum word)
         hipLaunchKernelGGL(k_xxh32_content, dim3(1), dim3(64), 0, st, (const uint8_t*)j.d_dst, 0ull, (uint8_t*)j.d_frame, (ResultRec*)d_res, 1u);
     tick(7, true);

@@ -376,13 +376,22 @@ __global__ __launch_bounds__(256) void k_walk_cand(const uint8_t* __restrict__ f
     __syncthreads();
     // a size word's upper bits: bit 31 may be set (stored block), the count is <= bs
     const uint32_t hi_mask = ~((bs << 1) - 1u) & 0x7FFFFFFFu;       // bits that must be clear (bs itself is allowed: checked by walk_step)
-    for (uint32_t o = threadIdx.x * 16; o < WK_CHUNK; o += 256 * 16) {
-        const uint64_t p0 = c0 + o;
-        if (p0 + 4 > frame_cap) break;
-        // 20 bytes: my 16 positions' words (guarded at the frame's end)
-        uint32_t w[5] = {0, 0, 0, 0, 0};
+    // 20 bytes: a thread's 16 positions' words (guarded at the frame's end); four pieces are asked for before the first is
+    // looked at - one 16-byte load in flight per thread is a sixth of what the memory system needs to stream
+    auto load20 = [&](uint64_t p0, uint32_t (&w)[5]) {
+        w[0] = w[1] = w[2] = w[3] = w[4] = 0;
+        if (p0 + 4 > frame_cap) return;
         if (p0 + 20 <= frame_cap) { const b16_ua t = *(const b16_ua*)(frame + p0); w[0] = t.a; w[1] = t.b; w[2] = t.c; w[3] = t.d; w[4] = *(const u32_ua*)(frame + p0 + 16); }
         else { for (uint32_t k = 0; k < 20 && p0 + k < frame_cap; k++) w[k >> 2] |= (uint32_t)frame[p0 + k] << (8 * (k & 3)); }
+    };
+    auto scan16 = [&](uint32_t o, const uint32_t (&w)[5]) {
+        const uint64_t p0 = c0 + o;
+        if (p0 + 4 > frame_cap) return;
+        // a size word's top byte is 0x00 or 0x80 for every block size there is: if none of the 16 positions' top bytes (bytes 3..18
+        // of the 20) is, there is nothing to look at - which is the case nearly everywhere in text, and what makes this pass a
+        // streaming read there.  (SWAR zero-byte test on x & 0x7F7F7F7F; a borrow can only add false alarms.)
+        auto zb = [](uint32_t x) { const uint32_t y = x & 0x7F7F7F7Fu; return (y - 0x01010101u) & 0x80808080u; };
+        if (((zb(w[0]) & 0x80000000u) | zb(w[1]) | zb(w[2]) | zb(w[3]) | (zb(w[4]) & 0x00808080u)) == 0u) return;
 #pragma unroll
         for (uint32_t i = 0; i < 16; i++) {
             const uint32_t sh = (i & 3) * 8;
@@ -397,6 +406,12 @@ __global__ __launch_bounds__(256) void k_walk_cand(const uint8_t* __restrict__ f
             const uint32_t at = atomicAdd(&s_n, 1u);
             if (at < WK_SLOTS) s_off[at] = o + i;
         }
+    };
+    constexpr uint32_t STRIDE = 256 * 16;                              // (WK_CHUNK = 16 strides: four rounds of four)
+    for (uint32_t o = threadIdx.x * 16; o < WK_CHUNK; o += 4 * STRIDE) {
+        uint32_t wa[5], wb[5], wc[5], wd[5];
+        load20(c0 + o, wa); load20(c0 + o + STRIDE, wb); load20(c0 + o + 2 * STRIDE, wc); load20(c0 + o + 3 * STRIDE, wd);
+        scan16(o, wa); scan16(o + STRIDE, wb); scan16(o + 2 * STRIDE, wc); scan16(o + 3 * STRIDE, wd);
     }
     __syncthreads();
     if (threadIdx.x == 0) chunks[blockIdx.x].n = s_n;
@@ -651,24 +666,47 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG, 8) void k_decode_blocks(const ui
 }
 
 // totals + status; compacts the output if a non-final block of an independent frame decoded short
+// What k_finish_decode has to know about the block table, found by a thread per block instead of one wave walking it 64
+// entries per dependent load (16384 blocks: 0.22 ms): the first failed block, whether every block already sits where its
+// predecessors end (independent frames: all blocks but the last decoded to full size, at b * blockSize), the sum of the sizes.
+//   w[0] block-checksum verdict (k_xxh32_blocks), w[1] first failed block (preset 0xFFFFFFFF), w[2] != 0: something has to move,
+//   w[4..5] sum of the decoded sizes (preset 0)
+__global__ __launch_bounds__(256) void k_finish_check(const BlockOut* __restrict__ table, const ResultRec* __restrict__ res, uint32_t n_max,
+                                                      uint32_t linked, uint32_t block_size, uint32_t* __restrict__ w)
+{
+    if (res->status != ST_OK) return;
+    const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    const uint32_t b = blockIdx.x * 256u + threadIdx.x, lane = lane_id();
+    const bool in = b < n;
+    const uint32_t sz = in ? table[b].dst_size : 0u;
+    const uint64_t at = in ? table[b].dst_off : 0ull;
+    const bool bad = in && (int32_t)sz < 0;
+    if (bad) atomicMin(&w[1], b);
+    const bool moves = in && !linked && (at != (uint64_t)b * block_size || (b + 1 < n && sz != block_size));
+    const uint64_t mv = __ballot(moves);
+    uint32_t sum = bad ? 0u : sz;                                      // (<= 64 * 4 MiB per wave: fits)
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) sum += __shfl_xor(sum, sft);
+    if (lane == 0) {
+        if (mv) atomicOr(&w[2], 1u);
+        if (sum) atomicAdd((unsigned long long*)(w + 4), (unsigned long long)sum);
+    }
+}
+
 __global__ __launch_bounds__(64) void k_finish_decode(uint8_t* dst, BlockOut* __restrict__ table, ResultRec* res, uint32_t n_max,
-                                                      uint32_t linked, uint32_t block_size, const uint32_t* __restrict__ bad_ck,
+                                                      uint32_t linked, uint32_t block_size, const uint32_t* __restrict__ bad_ck, uint32_t with_ck,
                                                       uint32_t plan = 0, const uint32_t* __restrict__ ix_flags = nullptr)
 {
     // which way the call went (lz4f_mi355x.h: LZ4F_MI355X_PATH_*): what the host launched, and whether the indexed kernels gave up
     if (lane_id() == 0) res->flags = (res->flags & 0xFFFu) | (plan << 12) | ((ix_flags && *ix_flags) ? (LZ4F_MI355X_PATH_INDEX_DROPPED << 12) : 0u);
     if (res->status != ST_OK) return;
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    uint32_t n_scan = n;
     const uint32_t lane = lane_id();
-    // first failed block
-    uint32_t first_bad = 0xFFFFFFFFu, bad_kind = 0;
-    for (uint32_t b0 = 0; b0 < n; b0 += WAVE) {
-        const uint32_t b = b0 + lane;
-        const bool bad = b < n && (int32_t)table[b].dst_size < 0;
-        const uint64_t m = __ballot(bad);
-        if (m) { const uint32_t f = (uint32_t)__builtin_ctzll(m); first_bad = b0 + f; bad_kind = __builtin_amdgcn_readlane(b < n ? table[b].dst_size : 0u, f); break; }
-    }
-    const uint32_t ck = bad_ck ? *bad_ck : 0xFFFFFFFFu;
+    // first failed block (k_finish_check)
+    const uint32_t first_bad = bad_ck[1] < n ? bad_ck[1] : 0xFFFFFFFFu;
+    const uint32_t bad_kind = first_bad != 0xFFFFFFFFu ? table[first_bad].dst_size : 0u;
+    const uint32_t ck = with_ck ? bad_ck[0] : 0xFFFFFFFFu;
     if (ck != 0xFFFFFFFFu && ck <= first_bad) {
         if (lane == 0) { res->status = ST_BLOCKCK; res->first_bad_block = ck; }
         return;
@@ -679,9 +717,11 @@ __global__ __launch_bounds__(64) void k_finish_decode(uint8_t* dst, BlockOut* __
     }
     // usual case, checked 64 blocks per step: every block already sits where its predecessors end (all blocks but
     // the last decoded to full size), so nothing has to move and the total is a sum
-    uint64_t out = 0;
-    bool in_place = true;
-    for (uint32_t b0 = 0; b0 < n; b0 += WAVE) {
+    uint64_t out = *(const uint64_t*)(bad_ck + 4);
+    bool in_place = bad_ck[2] == 0;
+    if (!in_place) { out = 0; in_place = true; }                       // (k_finish_check's rule is stricter than needed: look properly)
+    else n_scan = 0;
+    for (uint32_t b0 = 0; b0 < n_scan; b0 += WAVE) {
         const uint32_t b = b0 + lane;
         const uint32_t sz = b < n ? table[b].dst_size : 0u;
         const uint64_t at = b < n ? table[b].dst_off : 0ull;
