@@ -161,9 +161,9 @@ size_t pipe_decompress_frame(const uint8_t* s, size_t n, const ParsedHeader& ph,
         Slots slots;
         // a linked frame is a chain from slab to slab (each needs the last 64 KiB the one before produced): one engine
         const bool parallel = !linked && nslab >= 2;
-        // (three engines per device: a block's parse is a ~2.5 ms chain however few blocks a slab has, so two slabs' kernels
-        // must fit beside a third one's download)
-        size_t r = slots.init(parallel ? bulk_devices() : 1, parallel ? (nslab >= 3 ? 3 : 2) : 1);
+        // (four engines per device: a block's parse is a ~2.5 ms chain however few blocks a slab has - upload 0.6 + kernels 2.5 +
+        // download 1.2 ms per 64 MiB slab - so it takes four slabs in flight to keep the download link busy; three gave 39 GiB/s, five 41, four 44)
+        size_t r = slots.init(parallel ? bulk_devices() : 1, parallel ? (nslab >= 4 ? 4 : nslab >= 3 ? 3 : 2) : 1);
         if (is_err(r)) return r;
         const size_t nslot = std::min(slots.eng.size(), nslab);
         std::vector<std::string> errs(nslot);
