@@ -896,14 +896,31 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_emit_gather(const uint8_t
             const uint32_t mlen = (uint32_t)((x >> 24) & 0xFFFFFFu), off = (uint32_t)(x >> 48);
             if (r == 0) lit += ci.carry_in;
             const uint32_t mcode = mlen - MINMATCH;
-            if (lane == 0) *o = (uint8_t)(((lit < 15 ? lit : 15) << 4) | (mcode < 15 ? mcode : 15));
-            o += 1;
-            if (lit >= 15) { emit_len_ext(o, lit - 15); o += len_ext_bytes(lit); }
-            wave_copy_disjoint(o, lp, lit);
-            o += lit;
-            if (lane == 0) { o[0] = (uint8_t)off; o[1] = (uint8_t)(off >> 8); }
-            o += 2;
-            if (mcode >= 15) { emit_len_ext(o, mcode - 15); o += len_ext_bytes(mcode); }
+            const uint32_t token = ((lit < 15 ? lit : 15) << 4) | (mcode < 15 ? mcode : 15);
+            // The control bytes - token + literal-length bytes in front of the literals, offset + match-length bytes behind them -
+            // go out as two stores of ALL lanes: lane i writes byte i, the lanes beyond the last byte write that last byte again
+            // (same address, same value).  As `if (lane == 0)` blocks and a loop per length they were four exec-mask blocks and
+            // ~40 scalar instructions per record, and this kernel's limit on such data is the CU's scalar unit (73 % busy).
+            const uint32_t hb = 1 + len_ext_bytes(lit), tb = 2 + len_ext_bytes(mcode);
+            if (hb <= WAVE && tb <= WAVE) {
+                const uint32_t hi = lane < hb - 1 ? lane : hb - 1, ti = lane < tb - 1 ? lane : tb - 1;
+                const uint32_t lrest = lit >= 15 ? (lit - 15) % 255 : 0u, mrest = mcode >= 15 ? (mcode - 15) % 255 : 0u;
+                o[hi] = (uint8_t)(hi == 0 ? token : hi < hb - 1 ? 255u : lrest);
+                o += hb;
+                wave_copy_disjoint(o, lp, lit);
+                o += lit;
+                o[ti] = (uint8_t)(ti == 0 ? off : ti == 1 ? off >> 8 : ti < tb - 1 ? 255u : mrest);
+                o += tb;
+            } else {
+                if (lane == 0) *o = (uint8_t)token;
+                o += 1;
+                if (lit >= 15) { emit_len_ext(o, lit - 15); o += len_ext_bytes(lit); }
+                wave_copy_disjoint(o, lp, lit);
+                o += lit;
+                if (lane == 0) { o[0] = (uint8_t)off; o[1] = (uint8_t)(off >> 8); }
+                o += 2;
+                if (mcode >= 15) { emit_len_ext(o, mcode - 15); o += len_ext_bytes(mcode); }
+            }
             lp += lit + mlen;
         }
         o_off = (uint64_t)(o - dst); lp_off = (uint64_t)(lp - src);
