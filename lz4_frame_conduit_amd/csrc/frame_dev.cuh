@@ -392,15 +392,24 @@ __global__ __launch_bounds__(256) void k_walk_cand(const uint8_t* __restrict__ f
         // streaming read there.  (SWAR zero-byte test on x & 0x7F7F7F7F; a borrow can only add false alarms.)
         auto zb = [](uint32_t x) { const uint32_t y = x & 0x7F7F7F7Fu; return (y - 0x01010101u) & 0x80808080u; };
         if (((zb(w[0]) & 0x80000000u) | zb(w[1]) | zb(w[2]) | zb(w[3]) | (zb(w[4]) & 0x00808080u)) == 0u) return;
+        // which of the 16 words could be size words (a bit each), then only those are followed - in a loop, not 16 inlined copies:
+        // this kernel was 40 KB of code, more than the instruction cache, and streamed at a third of what a plain read does
+        uint32_t plausible = 0;
 #pragma unroll
         for (uint32_t i = 0; i < 16; i++) {
             const uint32_t sh = (i & 3) * 8;
             const uint32_t v = sh ? (w[i >> 2] >> sh) | (w[(i >> 2) + 1] << (32 - sh)) : w[i >> 2];
-            if ((v & hi_mask) != 0 || v == 0) continue;               // (the EndMark is an end, not a block)
+            plausible |= ((v & hi_mask) == 0 && v != 0) ? 1u << i : 0u;   // (the EndMark is an end, not a block)
+        }
+#pragma unroll 1
+        while (plausible) {
+            const uint32_t i = (uint32_t)__builtin_ctz(plausible);
+            plausible &= plausible - 1;
             const uint64_t p = p0 + i;
             if (p < hsize || p + 4 > frame_cap) continue;
             // a chain of WK_HOPS plausible words (or fewer, up to the EndMark) from here
             uint64_t q = p, nx = 0; bool end = false, good = true;
+#pragma unroll 1
             for (uint32_t h = 0; h < WK_HOPS && good && !end; h++) { good = walk_step(frame, frame_cap, bs, bck, q, nx, end); if (h == 0 && end) good = false; q = nx; }
             if (!good) continue;
             const uint32_t at = atomicAdd(&s_n, 1u);
