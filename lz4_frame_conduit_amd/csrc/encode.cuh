@@ -509,6 +509,55 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                     E1DBG(const unsigned long long z2 = clock64(); a_probe += z2 - z1;)
                     if (!m) { ip = two ? ipB + WAVE * stepB : ipB; step += 1 + two; two = 1; continue; }
                     E1DBG(n_hit++;)
+                    // ---- dense data (text: a match every ~13 bytes): all the matches of this step at once ----
+                    // One match per step means ~6 steps per 64 positions, each a dozen LDS round trips and ~150 scalar instructions.
+                    // Here every lane with a verified candidate measures its own match (up to 20 bytes forwards, 4 backwards), the scalar
+                    // unit only hops from a match's end to the next lane with one - the greedy parse, as liblz4 would walk it - and the
+                    // chosen lanes write their records themselves.  A match of 20 bytes or more ends the pass and is taken by the code
+                    // below, which extends it as far as it goes.
+                    if (!inB && mode == 2 && step == 1) {
+                        const uint32_t di = ((mr >> lane) & 1ull) ? 1u : distA;
+                        const uint64_t x0 = e1_ld64(sh.ring, pA + 4) ^ e1_ld64(sh.ring, pA + 4 - di);
+                        const uint64_t x1 = e1_ld64(sh.ring, pA + 12) ^ e1_ld64(sh.ring, pA + 12 - di);
+                        const uint32_t xb = e1_ld32(sh.ring, pA - 4) ^ e1_ld32(sh.ring, pA - 4 - di);
+                        const uint32_t g0 = x0 ? (uint32_t)(__builtin_ctzll(x0) >> 3) : 8u, g1 = x1 ? (uint32_t)(__builtin_ctzll(x1) >> 3) : 8u;
+                        const uint32_t fraw = 4u + g0 + (g0 == 8u ? g1 : 0u), flim = end_lim - pA;         // (a probing lane has pA + 4 <= end_lim)
+                        const uint32_t fl = fraw < flim ? fraw : flim;
+                        const uint32_t lng = (fraw >= 20u && flim > 20u) ? 1u : 0u;
+                        const uint32_t nbk = xb ? (uint32_t)(__builtin_clz(xb) >> 3) : 4u;                   // bytes in front that agree
+                        if (!(uint32_t)__builtin_amdgcn_readlane((int)lng, (int)L)) {
+                            uint64_t taken = 0, rem = m;
+                            uint32_t endrel = 0, stop_at = WAVE;
+                            for (;;) {
+                                const uint32_t sx = (uint32_t)__builtin_ctzll(rem);
+                                if ((uint32_t)__builtin_amdgcn_readlane((int)lng, (int)sx)) { stop_at = sx; break; }
+                                taken |= 1ull << sx;
+                                endrel = sx + (uint32_t)__builtin_amdgcn_readlane((int)fl, (int)sx);
+                                if (endrel >= WAVE) break;
+                                rem &= ~((1ull << endrel) - 1ull);
+                                if (!rem) break;
+                            }
+                            const bool is_t = (taken >> lane) & 1ull;
+                            const uint32_t pe = wave_excl_scan_max(is_t ? lane + fl : 0u);        // where the chosen match in front of me ends (0: none in this step)
+                            const uint32_t before = pe ? ip + pe : anchor;                       // ... as a position: my literals start there
+                            const uint32_t bfloor = pe ? ip + pe : (anchor > floor_b ? anchor : floor_b);
+                            uint32_t nb = nbk;
+                            if (pA - bfloor < nb) nb = pA - bfloor;
+                            if (pA - di - low < nb) nb = pA - di - low;
+                            const uint32_t rank = (uint32_t)__builtin_popcountll(taken & ((1ull << lane) - 1ull));
+                            if (is_t) myrec[nrec + rank] = pack_rec(pA - nb - before, fl + nb, di);
+                            nrec += (uint32_t)__builtin_popcountll(taken);
+                            anchor = ip + endrel;
+                            const uint32_t nrel = stop_at < WAVE ? stop_at : (endrel > WAVE ? endrel : WAVE);       // where the search goes on
+                            // the positions between the matches go into the table (the ones up to the first match are in already)
+                            const bool ins2 = actA && lane > L && lane < nrel && lane >= pe;
+                            *(ins2 ? &sh.table[hA] : (uint16_t*)&sh.idle[lane]) = (uint16_t)pA; *(ins2 ? &sh.tags[hA] : (uint8_t*)&sh.idle[lane]) = (uint8_t)tgA;
+                            ip += nrel;
+                            atomicMax(lane == 0 ? &sh.cov : &sh.idle[lane], anchor);
+                            step = 1; two = 1;
+                            continue;
+                        }
+                    }
                     const uint32_t dsel = ((mr >> lane) & 1ull) ? (inB ? stepB : step) : (inB ? distB : distA);
                     uint32_t mp = (uint32_t)__builtin_amdgcn_readlane(inB ? pB : pA, L);
                     const uint32_t d = (uint32_t)__builtin_amdgcn_readlane(dsel, L);
