@@ -438,7 +438,9 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                 const uint32_t had = uni(atomicMax(lane == 0 ? &sh.pieces[par] : &sh.idle[lane], ok_p));
                 for (uint32_t pc = had; pc < ok_p; pc++) e1_dma_piece(sh, src, org, ts + E1_TILE, pc);
             }
-            if (mode == 0 && si >= E1_PROBE_SLICES) {
+            // (decided when slice 2 x 16 is handed out: the sixteen waves take the first sixteen together, and their counts arrive when
+            // they are through - deciding at slice 16 saw no hits yet and called every run's first tile sparse)
+            if (mode == 0 && si >= 2 * E1_PROBE_SLICES) {
                 mode = uni(__hip_atomic_load(&sh.hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) > E1_DENSE_HITS ? 2u : 1u;
                 *(lane == 0 ? &sh.mode : &sh.idle[lane]) = mode;
             }
@@ -547,6 +549,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                             const uint32_t rank = (uint32_t)__builtin_popcountll(taken & ((1ull << lane) - 1ull));
                             if (is_t) myrec[nrec + rank] = pack_rec(pA - nb - before, fl + nb, di);
                             nrec += (uint32_t)__builtin_popcountll(taken);
+                            E1DBG(if (blockIdx.x == 0 && lane == 0) { atomicAdd((unsigned long long*)&scratch[E1_DBG_AT + 13], 1ull); atomicAdd((unsigned long long*)&scratch[E1_DBG_AT + 14], (unsigned long long)__builtin_popcountll(taken)); atomicAdd((unsigned long long*)&scratch[E1_DBG_AT + 15], (unsigned long long)(stop_at < WAVE ? stop_at : (endrel > WAVE ? endrel : WAVE))); })
                             anchor = ip + endrel;
                             const uint32_t nrel = stop_at < WAVE ? stop_at : (endrel > WAVE ? endrel : WAVE);       // where the search goes on
                             // the positions between the matches go into the table (the ones up to the first match are in already)
@@ -558,6 +561,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                             continue;
                         }
                     }
+                    E1DBG(if (blockIdx.x == 0 && lane == 0) { atomicAdd((unsigned long long*)&scratch[E1_DBG_AT + 4 + (inB ? 0 : mode != 2 ? 1 : step != 1 ? 2 : 3)], 1ull); })
                     const uint32_t dsel = ((mr >> lane) & 1ull) ? (inB ? stepB : step) : (inB ? distB : distA);
                     uint32_t mp = (uint32_t)__builtin_amdgcn_readlane(inB ? pB : pA, L);
                     const uint32_t d = (uint32_t)__builtin_amdgcn_readlane(dsel, L);

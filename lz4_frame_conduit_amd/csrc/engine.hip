@@ -262,6 +262,7 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
 #ifdef E1_DEBUG
             { unsigned long long d[256]; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(d, (uint8_t*)e1_scratch.p + (size_t)n_wg * 2 * E1_NSLICE * E1_REC_PER_SLICE * 8, 2048, hipMemcpyDeviceToHost) == hipSuccess) {
                 for (int w = 0; w < 16; w += 5) { unsigned long long* x = d + 16 + w * 8; if (x[6]) fprintf(stderr, "E1 wave %d: per tile cycles: merge %llu parse %llu waitB1 %llu dma-issue %llu dma-wait %llu waitB2 %llu (%llu tiles)\n", w, x[0]/x[6], x[1]/x[6], x[2]/x[6], x[3]/x[6], x[4]/x[6], x[5]/x[6], x[6]); unsigned long long* f = d + 160 + w * 6; fprintf(stderr, "   parse: dequeue %llu cycles x %llu, probe step %llu cycles x %llu, hit %llu cycles x %llu (per tile)\n", f[3] ? f[0]/f[3] : 0, f[3]/x[6], f[4] ? f[1]/f[4] : 0, f[4]/x[6], f[5] ? f[2]/f[5] : 0, f[5]/x[6]); }
+                fprintf(stderr, "E1 dense passes (workgroup 0): %llu, matches taken %llu, positions advanced %llu; one-match steps because: hit in B %llu, mode not dense %llu, step != 1 %llu, first match long %llu\n", d[13], d[14], d[15], d[4], d[5], d[6], d[7]);
                 fprintf(stderr, "E1 debug: bounds hit: dequeue %llu, probe %llu, backward %llu, forward %llu; probe ip/last %llx step/slice %llx; back room/nb %llx; fwd mp/fw %llx end_lim/d %llx\n", d[0], d[1], d[2], d[3], d[8], d[9], d[10], d[11], d[12]); } }
 #endif
         }
