@@ -308,12 +308,22 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                 const uint32_t sj = s_lo + j, n = nn[j];
                 const uint64_t* lst = spc + sj * E1_REC_PER_SLICE;
                 E1Walk w{ts + sj * E1_SLICE, cov, bend};
-                for (uint32_t r = 0; r < n; r++) {
-                    uint32_t st, ml;
-                    if (!w.step(r == 0 ? x01[j].x : r == 1 ? x01[j].y : lst[r], st, ml)) continue;
-                    if (kept == 0) { f_start = st; f_mlen = ml; }
-                    else body += seq_size(st - last_end, ml);
-                    last_end = st + ml; kept++;
+                // (two records per load, the next pair on its way while this one is looked at: a dense tile has ~10 records per list,
+                // and one at a time that was 130 dependent memory round trips per lane and merge - as long as the parse of the tile)
+                ulonglong2 cur = x01[j];
+                for (uint32_t r = 0; r < n; r += 2) {
+                    ulonglong2 nx2 = cur;
+                    if (r + 2 < n) nx2 = *(const ulonglong2*)(lst + r + 2);
+#pragma unroll
+                    for (uint32_t h = 0; h < 2; h++) {
+                        if (r + h >= n) break;
+                        uint32_t st, ml;
+                        if (!w.step(h ? cur.y : cur.x, st, ml)) continue;
+                        if (kept == 0) { f_start = st; f_mlen = ml; }
+                        else body += seq_size(st - last_end, ml);
+                        last_end = st + ml; kept++;
+                    }
+                    cur = nx2;
                 }
                 const uint32_t e = (sj < nslice) ? s_end[sj] : 0u; cov = e > cov ? e : cov;
             }
@@ -338,12 +348,20 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                 const uint32_t sj = s_lo + j, n = nn[j];
                 const uint64_t* lst = spc + sj * E1_REC_PER_SLICE;
                 E1Walk w{ts + sj * E1_SLICE, cov, bend};
-                for (uint32_t r = 0; r < n; r++) {
-                    const uint64_t x = r == 0 ? x01[j].x : r == 1 ? x01[j].y : lst[r];
-                    uint32_t st, ml;
-                    if (!w.step(x, st, ml)) continue;
-                    out[jn++] = pack_rec(st - le, ml, (uint32_t)(x >> 48));
-                    le = st + ml;
+                ulonglong2 cur = x01[j];
+                for (uint32_t r = 0; r < n; r += 2) {
+                    ulonglong2 nx2 = cur;
+                    if (r + 2 < n) nx2 = *(const ulonglong2*)(lst + r + 2);
+#pragma unroll
+                    for (uint32_t h = 0; h < 2; h++) {
+                        if (r + h >= n) break;
+                        const uint64_t x = h ? cur.y : cur.x;
+                        uint32_t st, ml;
+                        if (!w.step(x, st, ml)) continue;
+                        out[jn++] = pack_rec(st - le, ml, (uint32_t)(x >> 48));
+                        le = st + ml;
+                    }
+                    cur = nx2;
                 }
                 const uint32_t e = (sj < nslice) ? s_end[sj] : 0u; cov = e > cov ? e : cov;
             }
