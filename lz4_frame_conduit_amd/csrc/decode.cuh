@@ -134,28 +134,6 @@ __device__ __forceinline__ int32_t wave_decode_block(const uint8_t* __restrict__
 // offset are four v_readlane and a funnel shift instead of scalar loads; short literal runs come out of the window by
 // ds_bpermute; the next window is on its way while this one is parsed).  Same accept/reject rules as wave_decode_block.
 //   readable: bytes that may be read from `in` on (the frame's end), >= csize
-__device__ __forceinline__ uint32_t dpp_incl_scan_add(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112 /* row_shr:2 */, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114 /* row_shr:4 */, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118 /* row_shr:8 */, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
-    return v;
-}
-__device__ __forceinline__ uint32_t dpp_incl_scan_max(uint32_t v)     // (identity 0)
-{
-    uint32_t t;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true); v = t > v ? t : v;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true); v = t > v ? t : v;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true); v = t > v ? t : v;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true); v = t > v ? t : v;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;
-    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;
-    return v;
-}
-
 template <bool VEC>
 __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable,
                                                          uint8_t* out, uint32_t cap, uint32_t* expand /* 64 words of LDS, this wave's */)

@@ -545,20 +545,22 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                         const uint32_t fl = fraw < flim ? fraw : flim;
                         const uint32_t lng = (fraw >= 20u && flim > 20u) ? 1u : 0u;
                         const uint32_t nbk = xb ? (uint32_t)(__builtin_clz(xb) >> 3) : 4u;                   // bytes in front that agree
-                        if (!(uint32_t)__builtin_amdgcn_readlane((int)lng, (int)L)) {
+                        const uint32_t flx = fl | (lng << 31);                                 // (one v_readlane per hop)
+                        if (!((uint32_t)__builtin_amdgcn_readlane((int)flx, (int)L) >> 31)) {
                             uint64_t taken = 0, rem = m;
                             uint32_t endrel = 0, stop_at = WAVE;
                             for (;;) {
                                 const uint32_t sx = (uint32_t)__builtin_ctzll(rem);
-                                if ((uint32_t)__builtin_amdgcn_readlane((int)lng, (int)sx)) { stop_at = sx; break; }
+                                const uint32_t fx = (uint32_t)__builtin_amdgcn_readlane((int)flx, (int)sx);
+                                if (fx >> 31) { stop_at = sx; break; }
                                 taken |= 1ull << sx;
-                                endrel = sx + (uint32_t)__builtin_amdgcn_readlane((int)fl, (int)sx);
+                                endrel = sx + fx;
                                 if (endrel >= WAVE) break;
                                 rem &= ~((1ull << endrel) - 1ull);
                                 if (!rem) break;
                             }
                             const bool is_t = (taken >> lane) & 1ull;
-                            const uint32_t pe = wave_excl_scan_max(is_t ? lane + fl : 0u);        // where the chosen match in front of me ends (0: none in this step)
+                            const uint32_t pe = dpp_excl_scan_max(is_t ? lane + fl : 0u);         // where the chosen match in front of me ends (0: none in this step)
                             const uint32_t before = pe ? ip + pe : anchor;                       // ... as a position: my literals start there
                             const uint32_t bfloor = pe ? ip + pe : (anchor > floor_b ? anchor : floor_b);
                             uint32_t nb = nbk;
@@ -576,6 +578,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                             ip += nrel;
                             atomicMax(lane == 0 ? &sh.cov : &sh.idle[lane], anchor);
                             step = 1; two = 1;
+                            E1DBG(a_hit += clock64() - z2;)
                             continue;
                         }
                     }
