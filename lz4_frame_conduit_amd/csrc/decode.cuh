@@ -286,7 +286,7 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
                 const uint32_t mtotal = (uint32_t)__builtin_amdgcn_readlane((int)mincl, 63);
                 const uint32_t md0 = (uint32_t)__builtin_amdgcn_readlane((int)mdst, 0);          // the window's first match: everything in front of it is stored or on its way
                 const bool indep = is_tok && mdst - off + mlen <= md0;                          // (implies off >= mlen: no overlap with itself either)
-                const uint32_t pa_mine = mdst | (mlen << 20);
+                const uint32_t pa_mine = mdst | (mlen << 24);                             // (a block is at most 4 MiB: 22 bits)
                 volatile uint32_t* const xp = expand;                         // (volatile: see below)
                 for (uint32_t base = 0; base < mtotal;) {                     // rounds of up to 64 match bytes, cut between matches
                     const bool fits = is_tok && mex >= base && mincl <= base + WAVE;
@@ -300,8 +300,8 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
                     const uint32_t kk = ((k1 ? k1 : 1u) - 1u) << 2;
                     const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)kk, (int)pa_mine),
                                    pb = (uint32_t)__builtin_amdgcn_ds_bpermute((int)kk, (int)(off | ((mex - base) << 16)));
-                    const uint32_t bi = lane - (pb >> 16), bd = pa & 0xFFFFFu;                 // my byte within the match, the match's destination
-                    if (k1 && bi < (pa >> 20)) { const uint8_t b = out[bd - (pb & 0xFFFFu) + bi]; out[bd + bi] = b; }
+                    const uint32_t bi = lane - (pb >> 16), bd = pa & 0xFFFFFFu;                // my byte within the match, the match's destination
+                    if (k1 && bi < (pa >> 24)) { const uint8_t b = out[bd - (pb & 0xFFFFu) + bi]; out[bd + bi] = b; }
                     base = nbase;
                 }
                 const bool together = indep;

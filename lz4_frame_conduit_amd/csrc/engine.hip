@@ -85,7 +85,7 @@ void lz4f_mi355x_engine::Switches::read()
     no_index = on("LZ4F_MI355X_NO_INDEX"); no_selfindex = on("LZ4F_MI355X_NO_SELFINDEX"); no_resolve = on("LZ4F_MI355X_NO_RESOLVE");
     no_trace = on("LZ4F_MI355X_NO_TRACE"); no_doubling = on("LZ4F_MI355X_NO_DOUBLING"); trace_always = on("LZ4F_MI355X_TRACE_ALWAYS");
     no_groups = on("LZ4F_MI355X_NO_GROUPS"); no_window = on("LZ4F_MI355X_NO_WINDOW"); serial_walk = on("LZ4F_MI355X_SERIAL_WALK");
-    no_trailer = on("LZ4F_MI355X_NO_TRAILER"); no_content_check = on("LZ4F_MI355X_NO_CONTENT_CHECK"); prof = on("LZ4F_MI355X_PROF"); e1_sync = on("LZ4F_MI355X_E1_SYNC");
+    no_trailer = on("LZ4F_MI355X_NO_TRAILER"); no_density_probe = on("LZ4F_MI355X_NO_DENSITY_PROBE"); no_content_check = on("LZ4F_MI355X_NO_CONTENT_CHECK"); prof = on("LZ4F_MI355X_PROF"); e1_sync = on("LZ4F_MI355X_E1_SYNC");
     chain_gate = 0; if (const char* v = getenv("LZ4F_MI355X_CHAIN_GATE")) { const int g = atoi(v); if (g > 0 && g < (1 << 20)) chain_gate = g; }
     decode_mode = 0; if (const char* v = getenv("LZ4F_MI355X_DECODE")) decode_mode = v[0];
     e1_run = 0; if (const char* v = getenv("LZ4F_MI355X_E1_RUN")) { const int g = atoi(v); if (g >= 1 && g <= 4096) e1_run = (unsigned)g; }
@@ -574,6 +574,16 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 }
             }
             plan |= LZ4F_MI355X_PATH_FUSED;
+            // big independent blocks and no index to go by: a look at the payload decides between the fused workgroups and - dense data -
+            // the wave-per-block decoder (k_density_probe); both are launched, one of them returns at once
+            if (!indexed && !j.linked && !sw.no_density_probe) {
+                if (density.ensure(64)) return make_err(LZ4F_ERROR_allocation_failed);
+                hipLaunchKernelGGL(k_density_probe, dim3(1), dim3(64), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, (uint32_t*)density.p);
+                hipLaunchKernelGGL((k_decode_blocks<W>), dim3((n_max + W - 1) / W), dim3(64 * W), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl, (const ResultRec*)d_res,
+                                   n_max, 0u, j.block_size, j.hist0, (uint64_t)j.frame_cap, (const uint32_t*)density.p);
+                only_if = (const uint32_t*)density.p + 1;
+                plan |= LZ4F_MI355X_PATH_WAVE_PER_BLOCK;
+            }
             if (small)
                 hipLaunchKernelGGL(k_decode_blocks_fused<FzCfg<4>>, dim3(n_max), dim3(64 * 4), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl,
                                    (const ResultRec*)d_res, n_max, 0u, j.block_size, j.hist0, prof, only_if);

@@ -625,16 +625,53 @@ __global__ void k_init_result(ResultRec* res, uint32_t n_blocks, uint32_t flags)
 }
 __global__ void k_set_block(BlockOut* t, BlockOut e) { if (threadIdx.x == 0 && blockIdx.x == 0) *t = e; }
 
+// Which decoder for a frame of big independent blocks that came without a usable index?  The fused workgroups parse on the scalar
+// unit - right for long sequences (a block of synth50 is 4 k of them), hopeless for text (320 k sequences per 4 MiB block: 190 ms
+// per GiB) - where the wave-per-block decoder, whose lanes find the tokens, takes a fifth of that although it leaves most of the
+// machine idle.  So 64 lanes each read the first 512 payload bytes of a block (spread over the frame) and count sequences:
+// under 24 payload bytes per sequence -> flags[0] = 1 (dense: k_decode_blocks), else flags[1] = 1 (k_decode_blocks_fused).
+__global__ __launch_bounds__(64) void k_density_probe(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
+                                                      const ResultRec* __restrict__ res, uint32_t n_max, uint32_t* __restrict__ flags)
+{
+    const uint32_t lane = lane_id();
+    uint32_t seqs = 0, bytes = 0;
+    const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    if (res->status == ST_OK && n) {
+        const uint32_t b = (uint32_t)(((uint64_t)lane * n) >> 6);
+        const BlockOut e = table[b];
+        const uint32_t csz = e.word & 0x7FFFFFFFu;
+        if (!(e.word >> 31) && csz >= 64 && e.src_off + csz <= frame_cap && (lane == 0 || b != (uint32_t)(((uint64_t)(lane - 1) * n) >> 6))) {
+            const uint8_t* in = frame + e.src_off;
+            const uint32_t lim = csz < 512u ? csz - 16u : 496u;
+            uint32_t pos = 0;
+            while (pos < lim && seqs < 256u) {                           // (lengths only; a malformed payload just gives a number)
+                const uint32_t t = in[pos++];
+                uint32_t lit = t >> 4;
+                if (lit == 15) { uint32_t x; do { x = pos < lim ? in[pos] : 0u; pos++; lit += x; } while (x == 255u && pos < lim); }
+                pos += lit + 2;
+                if ((t & 15u) == 15u) { uint32_t x; do { x = pos < lim ? in[pos] : 0u; pos++; } while (x == 255u && pos < lim); }
+                seqs++;
+            }
+            bytes = pos < 1024u ? pos : 1024u;
+        }
+    }
+    uint32_t st = seqs, bt = bytes;
+#pragma unroll
+    for (int sft = 1; sft < 64; sft <<= 1) { st += __shfl_xor(st, sft); bt += __shfl_xor(bt, sft); }
+    if (lane == 0) { const bool dense = st != 0 && bt < 24u * st; flags[0] = dense ? 1u : 0u; flags[1] = dense ? 0u : 1u; }
+}
+
 // `hist0`: valid bytes directly in front of dst (streaming API: the previous blocks' last 64 KiB).
 template <int WAVES_PER_WG>
 __global__ __launch_bounds__(64 * WAVES_PER_WG, 8) void k_decode_blocks(const uint8_t* __restrict__ frame, uint8_t* dst, uint64_t dst_cap,
                                                                      BlockOut* __restrict__ table, const ResultRec* __restrict__ res,
                                                                      uint32_t n_max, uint32_t linked, uint32_t block_size, uint64_t hist0,
-                                                                     uint64_t frame_cap)
+                                                                     uint64_t frame_cap, const uint32_t* __restrict__ only_if = nullptr)
 {
     __shared__ uint32_t expand[WAVES_PER_WG][64];
     const uint32_t w = uni(blockIdx.x * WAVES_PER_WG + (threadIdx.x >> 6));
     if (res->status != ST_OK) return;
+    if (only_if && *only_if == 0) return;                                // (k_density_probe sent the frame to the other decoder)
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
     const uint32_t lane = lane_id();
     if (!linked) {

@@ -871,7 +871,10 @@ def test_decode_path_by_input_class(L):
     s50, text = datagen.synth50(16 << 20, 21), datagen.synth_text(8 << 20, 22)
     def foreign(data, **kw): return oracle.conduit_compress(data.tobytes(), oracle.mkprefs(**kw))
     cases = {}      # name -> (kind, data, prefs kw, must have, must not have)
-    cases["foreign 4M independent"] = ("foreign", s50, dict(bsid=7, indep=1), P["fused"], P["table"] | P["trailer"] | P["parallel_walk"] | P["indexed"] | P["wave_per_block"] | P["window"])
+    # (big independent blocks without an index: fused workgroups AND the wave-per-block decoder are launched, a probe of the payload's
+    # density on the device lets one of them run - text goes to the lanes, long sequences to the fused parser)
+    cases["foreign 4M independent"] = ("foreign", s50, dict(bsid=7, indep=1), P["fused"] | P["wave_per_block"], P["table"] | P["trailer"] | P["parallel_walk"] | P["indexed"] | P["window"])
+    cases["foreign 4M independent text"] = ("foreign", text, dict(bsid=7, indep=1), P["fused"] | P["wave_per_block"], P["table"] | P["trailer"] | P["parallel_walk"] | P["indexed"] | P["window"])
     cases["foreign 64K independent"] = ("foreign", s50, dict(bsid=4, indep=1), P["parallel_walk"] | P["wave_per_block"], P["table"] | P["trailer"] | P["indexed"] | P["fused"])
     cases["foreign 64K independent, short"] = ("foreign", s50[:300000], dict(bsid=4, indep=1), P["wave_per_block"], P["parallel_walk"] | P["trailer"] | P["indexed"] | P["fused"])
     cases["foreign 64K linked"] = ("foreign", s50, dict(bsid=4, indep=0), P["self_index"] | P["indexed"] | P["window"] | P["fused"], P["table"] | P["trailer"] | P["wave_per_block"] | P["dropped"])
@@ -879,9 +882,9 @@ def test_decode_path_by_input_class(L):
     cases["in-band 4M"] = ("inband", s50, dict(bsid=7, indep=1), P["trailer"] | P["indexed"] | P["fused"], P["table"] | P["parallel_walk"] | P["self_index"] | P["doubling"] | P["dropped"])
     cases["in-band 64K"] = ("inband", s50, dict(bsid=4, indep=1), P["trailer"] | P["wave_per_block"], P["table"] | P["parallel_walk"] | P["indexed"] | P["fused"])
     # (text has more sequences than an index of the recommended size holds: the compressor marks it unusable, the trailer carries the block list alone)
-    cases["in-band 4M text"] = ("inband", text, dict(bsid=7, indep=1), P["trailer"] | P["fused"], P["table"] | P["indexed"] | P["hops"] | P["self_index"] | P["parallel_walk"])
+    cases["in-band 4M text"] = ("inband", text, dict(bsid=7, indep=1), P["trailer"] | P["fused"] | P["wave_per_block"], P["table"] | P["indexed"] | P["hops"] | P["self_index"] | P["parallel_walk"])
     cases["table + index 4M"] = ("indexed", s50, dict(bsid=7, indep=1), P["table"] | P["indexed"] | P["fused"], P["trailer"] | P["parallel_walk"] | P["self_index"] | P["dropped"])
-    cases["table 4M"] = ("table", s50, dict(bsid=7, indep=1), P["table"] | P["fused"], P["trailer"] | P["parallel_walk"] | P["indexed"])
+    cases["table 4M"] = ("table", s50, dict(bsid=7, indep=1), P["table"] | P["fused"] | P["wave_per_block"], P["trailer"] | P["parallel_walk"] | P["indexed"])
     made = {}
     def prepare(eng, name):
         kind, data, kw, _, _ = cases[name]
