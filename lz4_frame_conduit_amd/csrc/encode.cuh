@@ -130,6 +130,9 @@ static_assert(64 * E1_WAVES >= E1_NSLICE, "a thread per slice when the lists are
 #ifndef E1_GRAB_D
 #define E1_GRAB_D 1
 #endif
+#ifndef E1_DENSE_PASS
+#define E1_DENSE_PASS 1
+#endif
 constexpr uint32_t E1_GRAB_SPARSE = E1_GRAB, E1_GRAB_DENSE = E1_GRAB_D, E1_PROBE_SLICES = 16, E1_DENSE_HITS = 24;
 
 // 4 / 8 bytes at any byte position of the ring.  (A byte-unaligned ds_read_b32 / _b64 is legal on gfx950 but keeps the LDS busy
@@ -535,7 +538,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                     // unit only hops from a match's end to the next lane with one - the greedy parse, as liblz4 would walk it - and the
                     // chosen lanes write their records themselves.  A match of 20 bytes or more ends the pass and is taken by the code
                     // below, which extends it as far as it goes.
-                    if (!inB && mode == 2 && step == 1) {
+                    if (E1_DENSE_PASS && !inB && mode == 2 && step == 1) {
                         const uint32_t di = ((mr >> lane) & 1ull) ? 1u : distA;
                         const uint64_t x0 = e1_ld64(sh.ring, pA + 4) ^ e1_ld64(sh.ring, pA + 4 - di);
                         const uint64_t x1 = e1_ld64(sh.ring, pA + 12) ^ e1_ld64(sh.ring, pA + 12 - di);
