@@ -12,7 +12,8 @@ n_mut = int(sys.argv[2]) if len(sys.argv) > 2 else 150
 data = datagen.structured(1 << 20, 77) + datagen.synth50(1 << 20, 5).tobytes()
 if os.environ.get('DATA') == 'text':                # dense data: the frame goes through the pointer-doubling kernels
     data = datagen.synth_text(2 << 20, 7).tobytes()
-frame = oracle.conduit_compress(data, oracle.mkprefs(bsid=4, indep=0))
+# INDEP=1: independent blocks (64 KiB: the wave-per-block decoder whose lanes find the tokens; BSID=7: big blocks, density probe)
+frame = oracle.conduit_compress(data, oracle.mkprefs(bsid=int(os.environ.get("BSID", "4")), indep=1 if os.environ.get("INDEP") else 0))
 cap = len(data) + 8
 diff = 0; t0 = time.time()
 for i in range(n_mut):
