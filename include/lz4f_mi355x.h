@@ -232,7 +232,7 @@ LZ4F_MI355X_API size_t lz4f_mi355x_dev_workspace_size(size_t srcSize, const LZ4F
  * back to skip the serial walk over the size words.
  * Content checksum (prefs->frameInfo.contentChecksumFlag): XXH32 over the whole input is one
  * dependent chain, so ONE wave computes it (k_xxh32_content: the four accumulators as four
- * lanes) at ~2.4 GB/s - far below the codec; the word lands behind the EndMark as liblz4's does.  */
+ * lanes) at ~1.4 GB/s - far below the codec; the word lands behind the EndMark as liblz4's does.  */
 LZ4F_MI355X_API size_t lz4f_mi355x_dev_compressFrame(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity,
                                                      const void* d_src, size_t srcSize, const LZ4F_preferences_t* prefs,
                                                      lz4f_mi355x_result* d_result, lz4f_mi355x_block* d_table);

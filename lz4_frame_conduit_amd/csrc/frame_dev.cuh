@@ -108,8 +108,8 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_xxh32_blocks(uint8_t* fra
 // VALU instructions (v_add, v_alignbit, v_mul_lo: three per 16-byte stripe for all four) instead of one after the other on the
 // scalar unit (twenty).  Operands: the wave fetches 1 KiB per step (16 B per lane, coalesced), multiplies by P2 in all lanes,
 // parks the products in LDS stripe by stripe (four steps in flight), and lane c reads word c of every stripe back with immediate offsets
-// (ds_read_b32, independent of the chain).  Measured 15.7 cycles per stripe against 82 for the scalar form: ~2.4 GB/s per
-// payload.  Few big payloads (4 MiB blocks: 256 per GiB; the content checksum: ONE) are bound by exactly this; many small ones
+// (ds_read_b32, independent of the chain).  The probe's loop does 15.7 cycles per stripe against 82 for the scalar form; the
+// kernel ~23: ~1.4 GB/s per payload.  Few big payloads (4 MiB blocks: 256 per GiB; the content checksum: ONE) are bound by exactly this; many small ones
 // fill the machine with a wave each (wave_xxh32).  `len` is 64 bits: the content checksum runs over the whole stream (XXH32
 // adds the length modulo 2^32).  `park`: 2 KiB of LDS owned by the calling wave (two steps: the next one's products are
 // written while this one's are read).  The result is valid in every lane.
@@ -142,11 +142,13 @@ __device__ __forceinline__ uint32_t lane4_xxh32(const uint8_t* __restrict__ p, u
             store(r, half);                                                        // (the other half is what the previous step read: in-order LDS)
             const uint32_t n = (nstripes - s0 < WAVE) ? (uint32_t)(nstripes - s0) : WAVE;     // uniform
             const uint32_t* q = (const uint32_t*)((const uint8_t*)park + half * 1024u) + c;
+            // (the empty asm keeps hipcc from fusing this stripe's multiply with the next stripe's add into v_mad_u64_u32 - a 64-bit
+            // multiply-add that takes four passes: 34 cycles per stripe instead of 16)
             if (n == WAVE) {
 #pragma unroll
-                for (int i = 0; i < WAVE; i++) v = rotl32(v + q[i * 4], 13) * XP1;
+                for (int i = 0; i < WAVE; i++) { v = rotl32(v + q[i * 4], 13) * XP1; asm("" : "+v"(v)); }
             } else {
-                for (uint32_t i = 0; i < n; i++) v = rotl32(v + q[i * 4], 13) * XP1;
+                for (uint32_t i = 0; i < n; i++) { v = rotl32(v + q[i * 4], 13) * XP1; asm("" : "+v"(v)); }
             }
             half ^= 1u;
         };
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_xxh32_blocks4(uint8_t* fr
 }
 
 // The content checksum (Frame format "Content checksum"; LZ4F_compressEnd / LZ4F_decompress at the frame's end): XXH32 of the whole
-// stream, one chain by construction.  One wave (lane4_xxh32: ~2.4 GB/s, measured rate in DESIGN.md) - still half a second per GiB
+// stream, one chain by construction.  One wave (lane4_xxh32: ~1.4 GB/s, measured rate in DESIGN.md) - still 0.75 s per GiB
 // beside a codec that takes milliseconds, so a frame asks for it by its FLG bit and pays for it; the default prefs of the
 // reference's conduit (Conduit.hsc:205) leave it off.
 //   mode 0 (compress): `data` is the input; the word goes to the frame's last 4 bytes (res->size counts them already).
