@@ -288,9 +288,11 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
                 const bool indep = is_tok && mdst - off + mlen <= md0;                          // (implies off >= mlen: no overlap with itself either)
                 const uint32_t pa_mine = mdst | (mlen << 24);                             // (a block is at most 4 MiB: 22 bits)
                 volatile uint32_t* const xp = expand;                         // (volatile: see below)
-                for (uint32_t base = 0; base < mtotal;) {                     // rounds of up to 64 match bytes, cut between matches
+                uint32_t base = 0;
+                while (base < mtotal) {                                       // rounds of up to 64 match bytes, cut between matches
                     const bool fits = is_tok && mex >= base && mincl <= base + WAVE;
                     const uint64_t fm = __ballot(fits);                      // (never empty: a match here is at most 18 bytes)
+                    if (!fm) break;                                          // (... and if it ever were, the ordered loop behind takes what is left)
                     const uint32_t nbase = (uint32_t)__builtin_amdgcn_readlane((int)mincl, 63 - (int)__builtin_clzll(fm));
                     // to the compiler a lane that stores nothing in between reads back its own 0 - the other lanes' stores are not
                     // in its picture, hence volatile; same-wave LDS accesses are performed in order, so nothing else is needed
@@ -304,7 +306,7 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
                     if (k1 && bi < (pa >> 24)) { const uint8_t b = out[bd - (pb & 0xFFFFu) + bi]; out[bd + bi] = b; }
                     base = nbase;
                 }
-                const bool together = indep;
+                const bool together = indep && mex < base;                      // (copied by the rounds above)
                 uint64_t m = __ballot(is_tok && !together);                                    // the others, in order
                 while (m) {
                     const uint32_t k = (uint32_t)__builtin_ctzll(m);
