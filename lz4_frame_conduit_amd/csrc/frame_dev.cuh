@@ -242,8 +242,11 @@ __device__ uint32_t xxh32_small(const uint8_t* p, uint32_t len)   // len < 16: h
 __global__ void k_walk_frame(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint64_t dst_cap,
                              BlockOut* __restrict__ table, uint32_t table_cap, ResultRec* __restrict__ res, const uint32_t* __restrict__ walked = nullptr)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // One wave, every lane walking the same chain (all stores are of identical values to identical addresses): what the other 63
+    // lanes are there for is the read-ahead below.
+    if (threadIdx.x >= WAVE || blockIdx.x != 0) return;
     if (walked && *walked) return;                                      // the parallel walk (below) has written table and result
+    const uint32_t lane = lane_id();
     ResultRec r; r.size = 0; r.consumed = 0; r.status = ST_OK; r.n_blocks = 0; r.first_bad_block = 0xFFFFFFFFu; r.flags = 0;
     auto fail = [&](uint32_t st) { r.status = st; *res = r; };
     if (frame_cap < 7) return fail(12);                              // frameHeader_incomplete
@@ -273,9 +276,16 @@ __global__ void k_walk_frame(const uint8_t* __restrict__ frame, uint64_t frame_c
     if ((flg >> 3) & 1) content = (uint64_t)rd32_any(frame + 6) | ((uint64_t)rd32_any(frame + 10) << 32);
     uint64_t pos = hsize, out = 0;
     uint32_t n = 0;
+    // Every hop is a dependent read that misses every cache: 0.66 us per block (4 GiB in 4 MiB blocks: 0.68 ms).  Where the size word
+    // AFTER the next one will be is not known - but blocks of one stream are often of similar size, so the 64 lanes touch the 8 KiB
+    // around where it would be if the next block were as big as this one (a line each).  A right guess makes that hop an L2 hit, a
+    // wrong one costs nothing: the words read ahead are only looked at to keep the loads alive.
+    // (The read-ahead must not be waited for: memory operations return in order, so the next size word is asked for FIRST and the
+    // read-ahead behind it, and the wait is for all but the youngest - which the compiler cannot be told, hence the asm.  `ahead`
+    // stays a live register until the next pair is issued, by when it has arrived.)
+    if (frame_cap - pos < 4) return fail(12);
+    uint32_t w = *(const u32_ua*)(frame + pos), ahead = 0;
     for (;;) {
-        if (frame_cap - pos < 4) return fail(12);
-        const uint32_t w = rd32_any(frame + pos);
         pos += 4;
         if (w == 0) break;
         const uint32_t csz = w & 0x7FFFFFFFu;
@@ -288,7 +298,16 @@ __global__ void k_walk_frame(const uint8_t* __restrict__ frame, uint64_t frame_c
         out += bs;                                                  // provisional: full blocks (fixed up after decode)
         pos += (uint64_t)csz + 4 * bck;
         n++;
+        if (frame_cap - pos < 4) return fail(12);
+        const uint64_t guess = pos + 4 + csz + 4 * bck + (uint64_t)lane * 128u;          // lane 32 = the guess itself
+        const bool inside = guess >= 4096u + 4u && guess - 4096u + 4u <= frame_cap;
+        const uint8_t* pw = frame + pos;
+        const uint8_t* pa = inside ? frame + ((guess - 4096u) & ~(uint64_t)3) : pw;
+        asm volatile("" :: "v"(ahead));
+        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off\n\ts_waitcnt vmcnt(1)" : "=&v"(w), "=&v"(ahead) : "v"(pw), "v"(pa) : "memory");
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" :: "v"(ahead));
     if ((flg >> 2) & 1) { if (frame_cap - pos < 4) return fail(12); pos += 4; }   // content checksum: verified behind the decode (k_xxh32_content)
     r.n_blocks = n; r.consumed = pos; r.size = content;             // size = declared content size until decode fills it
     *res = r;
