@@ -239,14 +239,18 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
     };
     for (;;) {
         // ---- the lanes' path: a window of 64 payload bytes that starts at a token, away from the block's end ----
-        // (a token here costs >= 3 payload bytes and gives <= 14 + 18 output bytes: a window never makes more than 672; with 96
-        // payload bytes and 1 KiB of room left none of its sequences can be the last one or run into the end-of-block rules)
+        // (a token here costs >= 3 payload bytes and its match gives <= 18 output bytes, the literals are the window's own: a window
+        // never makes more than 64 + 21 * 18 = 442; with 96 payload bytes and 1 KiB of room left none of its sequences can be the
+        // last one or run into the end-of-block rules)
         if (VEC && pos <= csize && csize - pos >= 96u && cap - op >= 1024u) {
             typedef uint32_t u32_ua1 __attribute__((aligned(1)));
             const uint32_t d = dnext_pos == pos ? dnext : *(const u32_ua1*)(in + pos + lane);
-            const uint32_t t = d & 0xFFu, lit = t >> 4, ml = t & 15u;
-            const bool easy = lit != 15u && ml != 15u && lane + 3u + lit <= 64u;
-            const uint32_t nx = easy ? lane + 3u + lit : 255u;
+            // (a literal length of 15..269 - one extension byte - is still a lane's own business: the byte is in its dword.  Longer
+            // ones, and tokens with match-length bytes, go to one_sequence.)
+            const uint32_t t = d & 0xFFu, litn = t >> 4, ml = t & 15u, e1 = (d >> 8) & 0xFFu;
+            const uint32_t hdr = litn == 15u ? 2u : 1u, lit = litn == 15u ? 15u + e1 : litn;      // bytes in front of the literals; literals
+            const bool easy = ml != 15u && !(litn == 15u && e1 == 255u) && lane + hdr + lit + 2u <= 64u;
+            const uint32_t nx = easy ? lane + hdr + lit + 2u : 255u;
             // the serial part: one hop per token (v_readlane, s_bitset1, two moves, compare, branch).  A token is marked before its
             // end is known; the last one is taken back if it does not end inside the window.
             uint64_t mask = 0;
@@ -265,7 +269,7 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
                 if (csize - dnext_pos >= 96u) dnext = *(const u32_ua1*)(in + dnext_pos + lane); else dnext_pos = NONE;
                 const bool is_tok = (mask >> lane) & 1ull;
                 const uint32_t mlen = ml + 4u;
-                const uint32_t d2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + 1u + lit) << 2), (int)d);   // the dword of the lane the offset starts in
+                const uint32_t d2 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane + hdr + lit) << 2), (int)d);   // the dword of the lane the offset starts in
                 const uint32_t off = d2 & 0xFFFFu;
                 // one prefix sum for two spaces: the window's output bytes (low half) and its match bytes (high half; <= 672 and 378)
                 const uint32_t tout = is_tok ? lit + mlen : 0u, mcnt = is_tok ? mlen : 0u;
@@ -276,9 +280,9 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
                 if (__ballot(is_tok && (off == 0u || off > mdst))) return -1;
                 // literals: byte lane l belongs to the nearest token at or below it
                 const uint32_t g1 = dpp_incl_scan_max(is_tok ? lane + 1u : 0u);      // (lane 0 is a token: never 0)
-                const uint32_t pg = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((g1 - 1u) << 2), (int)((ex << 4) | lit));
-                const uint32_t r = lane - g1;                                // byte number within the token's literal run (wraps for the token byte itself)
-                if (lane >= g1 && r < (pg & 15u)) out[op + (pg >> 4) + r] = (uint8_t)d;
+                const uint32_t pg = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((g1 - 1u) << 2), (int)((ex << 8) | (lit << 1) | (hdr - 1u)));
+                const uint32_t r = lane - g1 - (pg & 1u);                    // byte number within the token's literal run (wraps for the token's own bytes)
+                if (lane >= g1 + (pg & 1u) && r < ((pg >> 1) & 127u)) out[op + (pg >> 8) + r] = (uint8_t)d;
                 // matches.  Most of them read what earlier windows wrote: those go together, 64 match bytes of the window per round, a
                 // lane per byte - a prefix sum places every match in that space, its lane leaves its number at the start of its run
                 // (`expand`, 64 words of LDS), a running maximum spreads it over the run.  A match whose source reaches into this
