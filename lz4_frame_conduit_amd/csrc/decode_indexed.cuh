@@ -269,6 +269,103 @@ __global__ __launch_bounds__(256) void k_selfindex_walk(const uint8_t* __restric
     if (MODE == 0) { cnt[b] = k; osz[b] = op; }
 }
 
+// The same walk with a WAVE per block and the lanes finding the tokens (decode.cuh: wave_decode_block_win without the copies): a
+// window of 64 payload bytes per step, every lane reading its byte as a token, the scalar unit hopping from token to token, a
+// prefix sum placing them - and the lanes whose sequence number is a multiple of IX_STRIDE writing their entry themselves.
+// Tokens with more than one literal-length byte or with match-length bytes, and the block's last ~100 bytes, go one at a time,
+// wave-uniformly.  Text in 64 KiB blocks: ~5000 sequences per block at ~1.3 us each for a lane (two passes: 13 ms per 256 MiB)
+// against ~14 per window here.  Same MODEs, same verdicts.
+template <int MODE, int WAVES_PER_WG>
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void k_selfindex_walk_wave(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
+                                                                           const ResultRec* __restrict__ res, uint32_t n_max, uint32_t* __restrict__ cnt,
+                                                                           uint32_t* __restrict__ osz, void* __restrict__ ix, uint32_t* __restrict__ flags)
+{
+    if (res->status != ST_OK || (MODE == 1 && *flags)) return;
+    const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    const uint32_t b = uni(blockIdx.x * WAVES_PER_WG + (threadIdx.x >> 6)), lane = lane_id();
+    if (b >= n) return;
+    const BlockOut e = table[b];
+    const uint32_t csize = e.word & 0x7FFFFFFFu;
+    if (e.word >> 31) { if (MODE == 0) { cnt[b] = 0; osz[b] = csize; } return; }
+    if (csize == 0 || e.src_off + csize > frame_cap) { atomicOr(flags, 1u); if (MODE == 0) { cnt[b] = 0; osz[b] = 0; } return; }
+    const uint8_t* in = frame + e.src_off;
+    const uint64_t readable = frame_cap - e.src_off;
+    IxEntry* ent = nullptr;
+    if (MODE == 1) { const IxBlock bk = ix_blocks((const void*)ix)[b]; ent = (IxEntry*)((uint8_t*)ix + ix_entries_at(n, ((const IxHeader*)ix)->chunks_per_block)) + bk.entry_base; }
+    const uint32_t total = MODE == 1 ? cnt[b] : 0u;
+    uint32_t pos = 0, op = 0, k = 0;
+    bool bad = false;
+    typedef uint32_t u32_ua1 __attribute__((aligned(1)));
+    for (;;) {
+        if (pos >= csize) { bad = true; break; }
+        // ---- the lanes' path (see wave_decode_block_win): tokens with at most one literal-length byte, ending inside the window ----
+        if (csize - pos >= 96u && op < (1u << 23)) {
+            const uint32_t d = *(const u32_ua1*)(in + pos + lane);
+            const uint32_t t = d & 0xFFu, litn = t >> 4, ml = t & 15u, e1 = (d >> 8) & 0xFFu;
+            const uint32_t hdr = litn == 15u ? 2u : 1u, lit = litn == 15u ? 15u + e1 : litn;
+            const bool easy = ml != 15u && !(litn == 15u && e1 == 255u) && lane + hdr + lit + 2u <= 64u;
+            const uint32_t nx = easy ? lane + hdr + lit + 2u : 255u;
+            uint64_t mask = 0;
+            uint32_t s = 0, sp = 0, nn;
+            do {
+                nn = (uint32_t)__builtin_amdgcn_readlane((int)nx, (int)s);
+                asm("s_bitset1_b64 %0, %1" : "+s"(mask) : "s"(s));
+                sp = s; s = nn;
+            } while (nn < 64u);
+            if (nn > 64u) { mask &= ~(1ull << sp); s = sp; }
+            if (mask) {
+                const bool is_tok = (mask >> lane) & 1ull;
+                const uint32_t tout = is_tok ? lit + ml + 4u : 0u;
+                const uint32_t incl = dpp_incl_scan_add(tout), ex = incl - tout;
+                const uint32_t rank = (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                if (MODE == 1) {
+                    const uint32_t kk = k + rank;
+                    if (is_tok && (kk % IX_STRIDE) == 0 && kk < total) ent[kk / IX_STRIDE] = IxEntry{pos + lane, op + ex, kk, (total - kk < IX_STRIDE ? total - kk : IX_STRIDE) | (b << 8)};
+                }
+                k += (uint32_t)__builtin_popcountll(mask);
+                op += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                pos += s;
+                if (op > (1u << 23)) { bad = true; break; }
+                continue;
+            }
+        }
+        // ---- one sequence, wave-uniformly (every lane the same loads) ----
+        if (MODE == 1 && (k % IX_STRIDE) == 0 && k < total) {
+            const uint32_t ns = total - k < IX_STRIDE ? total - k : IX_STRIDE;
+            ent[k / IX_STRIDE] = IxEntry{pos, op, k, ns | (b << 8)};
+        }
+        uint64_t w, w_hi;
+        pt_load16(in, pos, readable, w, w_hi);
+        const uint32_t token = (uint32_t)w & 0xFF;
+        uint32_t lit = token >> 4, p = pos + 1;
+        if (lit == 15) {
+            const uint64_t x = w >> 8;
+            const uint32_t f = (uint32_t)__builtin_ctzll(~x), kk = f >> 3;
+            if (kk < 7) { lit += 255u * kk + (uint32_t)((x >> (f & 56u)) & 0xFF); p += kk + 1; }
+            else { for (;;) { if (p >= csize || lit > (1u << 24)) { bad = true; break; } const uint32_t v = in[p++]; lit += v; if (v != 255) break; } if (bad) break; }
+        }
+        if (p > csize || lit >= (1u << 24)) { bad = true; break; }
+        const uint32_t in_left = csize - p;
+        k++;
+        if (lit + 8 > in_left) { if (lit != in_left) bad = true; op += lit; break; }       // the block's last sequence
+        const uint32_t q = p + lit;
+        uint64_t w2, w2_hi;
+        pt_load16(in, q, readable, w2, w2_hi);
+        uint32_t mlen = token & 15, pn = q + 2;
+        if (mlen == 15) {
+            const uint64_t x = w2 >> 16;
+            const uint32_t f = (uint32_t)__builtin_ctzll(~x), kk = f >> 3;
+            if (kk < 6) { mlen += 255u * kk + (uint32_t)((x >> (f & 56u)) & 0xFF); pn += kk + 1; }
+            else { for (;;) { if (pn >= csize || mlen > (1u << 24)) { bad = true; break; } const uint32_t v = in[pn++]; mlen += v; if (v != 255) break; } if (bad) break; }
+        }
+        op += lit + mlen + 4;
+        pos = pn;
+        if (op > (1u << 23)) { bad = true; break; }
+    }
+    if (bad || (MODE == 1 && k != total)) { atomicOr(flags, 1u); if (MODE == 0) { cnt[b] = 0; osz[b] = 0; } return; }
+    if (MODE == 0) { cnt[b] = k; osz[b] = op; }
+}
+
 // One workgroup: exclusive scans over the blocks (sequences, entries, output bytes) -> the index's block table and header,
 // and every block's place in the output.  flags[8] / flags[9] get the totals (the host reads them to size the workspaces).
 __global__ __launch_bounds__(1024) void k_selfindex_scan(BlockOut* __restrict__ table, const ResultRec* __restrict__ res, uint32_t n_max,

@@ -415,7 +415,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 return make_err(LZ4F_ERROR_allocation_failed);
             uint32_t* cnt = (uint32_t*)selfcnt.p; uint32_t* osz = cnt + n_max;
             HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 64, st));
-            hipLaunchKernelGGL(k_selfindex_walk<0>, dim3((n_max + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl,
+            hipLaunchKernelGGL((k_selfindex_walk_wave<0, 4>), dim3((n_max + 3) / 4), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl,
                                (const ResultRec*)d_res, n_max, cnt, osz, (void*)nullptr, (uint32_t*)seqcnt.p);
             uint32_t tot[10];
             for (int pass = 0; pass < 2; pass++) {
@@ -430,7 +430,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 if (selfix.p == before) break;                                   // (same buffer: the block table is already in it)
             }
             if (tot[0] == 0 && tot[9] != 0) {
-                hipLaunchKernelGGL(k_selfindex_walk<1>, dim3((n_max + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl,
+                hipLaunchKernelGGL((k_selfindex_walk_wave<1, 4>), dim3((n_max + 3) / 4), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl,
                                    (const ResultRec*)d_res, n_max, cnt, osz, selfix.p, (uint32_t*)seqcnt.p);
                 d_index = selfix.p; index_size = fixed + (size_t)tot[8] * sizeof(IxEntry);
                 self_indexed = true;
