@@ -211,9 +211,11 @@ __global__ __launch_bounds__(256) void k_parse_indexed(const uint8_t* __restrict
 template <int MODE>
 __global__ __launch_bounds__(256) void k_selfindex_walk(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
                                                         const ResultRec* __restrict__ res, uint32_t n_max, uint32_t* __restrict__ cnt,
-                                                        uint32_t* __restrict__ osz, void* __restrict__ ix, uint32_t* __restrict__ flags)
+                                                        uint32_t* __restrict__ osz, void* __restrict__ ix, uint32_t* __restrict__ flags,
+                                                        const uint32_t* __restrict__ only_if = nullptr)
 {
     if (res->status != ST_OK || (MODE == 1 && *flags)) return;
+    if (only_if && *only_if == 0) return;                                // (k_density_probe: dense payloads go to k_selfindex_walk_wave)
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= n) return;
@@ -274,13 +276,17 @@ __global__ __launch_bounds__(256) void k_selfindex_walk(const uint8_t* __restric
 // prefix sum placing them - and the lanes whose sequence number is a multiple of IX_STRIDE writing their entry themselves.
 // Tokens with more than one literal-length byte or with match-length bytes, and the block's last ~100 bytes, go one at a time,
 // wave-uniformly.  Text in 64 KiB blocks: ~5000 sequences per block at ~1.3 us each for a lane (two passes: 13 ms per 256 MiB)
-// against ~14 per window here.  Same MODEs, same verdicts.
+// against ~14 per window here.  Data with few sequences per block is the other way round - 65536 blocks of 64 sequences are 1024
+// waves of lanes all in flight at once (0.3 ms) but eight rounds of waves here (2.4 ms) - so k_density_probe picks.  Same MODEs,
+// same verdicts.
 template <int MODE, int WAVES_PER_WG>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_selfindex_walk_wave(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
                                                                            const ResultRec* __restrict__ res, uint32_t n_max, uint32_t* __restrict__ cnt,
-                                                                           uint32_t* __restrict__ osz, void* __restrict__ ix, uint32_t* __restrict__ flags)
+                                                                           uint32_t* __restrict__ osz, void* __restrict__ ix, uint32_t* __restrict__ flags,
+                                                                           const uint32_t* __restrict__ only_if = nullptr)
 {
     if (res->status != ST_OK || (MODE == 1 && *flags)) return;
+    if (only_if && *only_if == 0) return;                                // (k_density_probe: sparse payloads go to k_selfindex_walk, a lane per block)
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
     const uint32_t b = uni(blockIdx.x * WAVES_PER_WG + (threadIdx.x >> 6)), lane = lane_id();
     if (b >= n) return;

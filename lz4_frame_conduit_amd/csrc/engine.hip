@@ -415,8 +415,12 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 return make_err(LZ4F_ERROR_allocation_failed);
             uint32_t* cnt = (uint32_t*)selfcnt.p; uint32_t* osz = cnt + n_max;
             HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 64, st));
+            if (density.ensure(64)) return make_err(LZ4F_ERROR_allocation_failed);
+            hipLaunchKernelGGL(k_density_probe, dim3(1), dim3(64), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, (uint32_t*)density.p);
             hipLaunchKernelGGL((k_selfindex_walk_wave<0, 4>), dim3((n_max + 3) / 4), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl,
-                               (const ResultRec*)d_res, n_max, cnt, osz, (void*)nullptr, (uint32_t*)seqcnt.p);
+                               (const ResultRec*)d_res, n_max, cnt, osz, (void*)nullptr, (uint32_t*)seqcnt.p, (const uint32_t*)density.p);
+            hipLaunchKernelGGL(k_selfindex_walk<0>, dim3((n_max + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl,
+                               (const ResultRec*)d_res, n_max, cnt, osz, (void*)nullptr, (uint32_t*)seqcnt.p, (const uint32_t*)density.p + 1);
             uint32_t tot[10];
             for (int pass = 0; pass < 2; pass++) {
                 hipLaunchKernelGGL(k_selfindex_scan, dim3(1), dim3(1024), 0, st, tbl, (const ResultRec*)d_res, n_max, (const uint32_t*)cnt, (const uint32_t*)osz,
@@ -431,7 +435,9 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             }
             if (tot[0] == 0 && tot[9] != 0) {
                 hipLaunchKernelGGL((k_selfindex_walk_wave<1, 4>), dim3((n_max + 3) / 4), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl,
-                                   (const ResultRec*)d_res, n_max, cnt, osz, selfix.p, (uint32_t*)seqcnt.p);
+                                   (const ResultRec*)d_res, n_max, cnt, osz, selfix.p, (uint32_t*)seqcnt.p, (const uint32_t*)density.p);
+                hipLaunchKernelGGL(k_selfindex_walk<1>, dim3((n_max + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl,
+                                   (const ResultRec*)d_res, n_max, cnt, osz, selfix.p, (uint32_t*)seqcnt.p, (const uint32_t*)density.p + 1);
                 d_index = selfix.p; index_size = fixed + (size_t)tot[8] * sizeof(IxEntry);
                 self_indexed = true;
                 plan |= LZ4F_MI355X_PATH_SELF_INDEX;
