@@ -90,7 +90,9 @@ template <class C>
 __device__ __forceinline__ void fz_parser(FzShared<C>& sh, const uint8_t* __restrict__ in, uint32_t csize, uint32_t cap, uint64_t hist,
                                           unsigned long long* prof)
 {
+#ifdef FZ_PROF
     const unsigned long long t_begin = clock64(); unsigned long long t_ring = 0;
+#endif
     const uint32_t lane = lane_id();
     uint8_t* stages = &sh.stage[0][0];
     uint32_t nseq = 0, status = 0;
@@ -173,9 +175,13 @@ __device__ __forceinline__ void fz_parser(FzShared<C>& sh, const uint8_t* __rest
     };
     // publish the gathered descriptors as ring slot number `slot_idx`
     auto publish = [&](uint32_t slot_idx) {
+#ifdef FZ_PROF
         const unsigned long long tr = clock64();
+#endif
         while (slot_idx >= lds_peek(&sh.match_done) + C::RING) __builtin_amdgcn_s_sleep(8);    // ring full: wait for the oldest slot
+#ifdef FZ_PROF
         t_ring += clock64() - tr;
+#endif
         sh.ring[slot_idx % C::RING][lane] = uint4{d0, d1, d2, d3};
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         lds_poke(&sh.produced, slot_idx + 1);
@@ -263,7 +269,9 @@ __device__ __forceinline__ void fz_parser(FzShared<C>& sh, const uint8_t* __rest
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     lds_poke(&sh.finished, 1u);
     if (part) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lds_poke(&sh.produced, full + 1); }
+#ifdef FZ_PROF          // (the cycle stamps of the parser: a build switch, because they cost the loop six scalar registers)
     if (prof && blockIdx.x == 0 && lane == 0) { prof[0] = clock64() - t_begin; prof[1] = t_ring; prof[2] = nseq; }
+#endif
 }
 
 // ---------------- feeder wave (indexed decode, decode_indexed.cuh) ----------------

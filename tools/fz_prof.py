@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Dev tool (GPU box): cycle counters of the fused decoder's workgroup 0 (LZ4F_MI355X_PROF=1)."""
+"""Dev tool (GPU box): cycle counters of the fused decoder's workgroup 0 (LZ4F_MI355X_PROF=1; the parser's own stamps need a build with -DFZ_PROF)."""
 import ctypes, os, sys
 os.environ["LZ4F_MI355X_PROF"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
