@@ -513,7 +513,9 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                         const uint64_t n_thr = (trace_span + IXT_TB - 1) / IXT_TB;
                         // if the last index seen here was of a dense stream (the device decides about THIS one, but the
                         // scratch - 4 bytes per output byte - and 18 launches are the host's to spend): one hop per byte, then pointer doubling
-                        const bool doubling = can_double && !pdbuf.ensure((size_t)trace_span * 4 + 256 + (IXP_ROUNDS + 1) * IXP_STRIPES * 4);
+                        const uint32_t pd_grid = (uint32_t)((trace_span / 4 + 255) / 256), pd_ngrp = pd_grid * 4u;      // (k_pd_round: a wave per 256 bytes)
+                        const size_t pd_grp_at = (((size_t)trace_span * 4 + 255) & ~(size_t)255) + (((IXP_ROUNDS + 1) * IXP_STRIPES * 4 + 255) & ~(size_t)255);
+                        const bool doubling = can_double && !pdbuf.ensure(pd_grp_at + 2 * (size_t)pd_ngrp + 256);
                         if (doubling) {
                             plan |= LZ4F_MI355X_PATH_DOUBLING;
                             uint32_t* remaining = (uint32_t*)((uint8_t*)pdbuf.p + (((size_t)trace_span * 4 + 255) & ~(size_t)255));
@@ -522,8 +524,8 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                                                (const ResultRec*)d_res, n_ix, d_index, (const SeqDesc*)desc.p, (const uint32_t*)dsrc, (const uint32_t*)postab.p, (uint32_t*)seqcnt.p,
                                                lk & 1u, (uint32_t)j.block_size, (uint64_t)j.hist0, (uint32_t*)pdbuf.p, remaining);
                             for (uint32_t r = 1; r <= IXP_ROUNDS; r++)
-                                hipLaunchKernelGGL(k_pd_round, dim3((uint32_t)((trace_span / 4 + 255) / 256)), dim3(256), 0, st, j.d_dst, (uint32_t*)pdbuf.p, (const BlockOut*)tbl,
-                                                   (const ResultRec*)d_res, n_ix, r, remaining, (uint32_t*)seqcnt.p);
+                                hipLaunchKernelGGL(k_pd_round, dim3(pd_grid), dim3(256), 0, st, j.d_dst, (uint32_t*)pdbuf.p, (const BlockOut*)tbl,
+                                                   (const ResultRec*)d_res, n_ix, r, remaining, (uint32_t*)seqcnt.p, (uint8_t*)pdbuf.p + pd_grp_at, pd_ngrp);
                             hipLaunchKernelGGL(k_pd_verdict, dim3(1), dim3(64), 0, st, (uint32_t*)seqcnt.p, (const uint32_t*)remaining);
                             if (iprof) { static uint32_t t[(IXP_ROUNDS + 1) * IXP_STRIPES]; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(t, remaining, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) { fprintf(stderr, "doubling: bytes open after each round:"); for (uint32_t r = 0; r <= IXP_ROUNDS; r++) { uint64_t sum = 0; for (uint32_t q = 0; q < IXP_STRIPES; q++) sum += t[r * IXP_STRIPES + q]; fprintf(stderr, " %llu", (unsigned long long)sum); } fprintf(stderr, "\n"); } }
                         } else {
