@@ -248,7 +248,7 @@ __global__ void k_walk_frame(const uint8_t* __restrict__ frame, uint64_t frame_c
     if (walked && *walked) return;                                      // the parallel walk (below) has written table and result
     const uint32_t lane = lane_id();
     ResultRec r; r.size = 0; r.consumed = 0; r.status = ST_OK; r.n_blocks = 0; r.first_bad_block = 0xFFFFFFFFu; r.flags = 0;
-    auto fail = [&](uint32_t st) { r.status = st; *res = r; };
+    auto fail = [&](uint32_t st) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); r.status = st; *res = r; };      // (a read-ahead may be in flight)
     if (frame_cap < 7) return fail(12);                              // frameHeader_incomplete
     const uint32_t magic = rd32_any(frame);
     if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {                      // skippable frame: no output
