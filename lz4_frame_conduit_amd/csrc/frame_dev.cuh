@@ -649,7 +649,8 @@ __global__ void k_set_block(BlockOut* t, BlockOut e) { if (threadIdx.x == 0 && b
 // Which decoder for a frame of big independent blocks that came without a usable index?  The fused workgroups parse on the scalar
 // unit - right for long sequences (a block of synth50 is 4 k of them), hopeless for text (320 k sequences per 4 MiB block: 190 ms
 // per GiB) - where the wave-per-block decoder, whose lanes find the tokens, takes a fifth of that although it leaves most of the
-// machine idle.  So 64 lanes each read the first 512 payload bytes of a block (spread over the frame) and count sequences:
+// machine idle.  So 64 lanes each read the first 512 payload bytes of a block (spread over the frame) and count sequences - not
+// the first one, which is the literal run of a block that has nothing to refer to yet (at 192 bytes it alone made text look sparse):
 // under 24 payload bytes per sequence -> flags[0] = 1 (dense: k_decode_blocks), else flags[1] = 1 (k_decode_blocks_fused).
 __global__ __launch_bounds__(64) void k_density_probe(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
                                                       const ResultRec* __restrict__ res, uint32_t n_max, uint32_t* __restrict__ flags)
@@ -664,7 +665,7 @@ __global__ __launch_bounds__(64) void k_density_probe(const uint8_t* __restrict_
         if (!(e.word >> 31) && csz >= 64 && e.src_off + csz <= frame_cap && (lane == 0 || b != (uint32_t)(((uint64_t)(lane - 1) * n) >> 6))) {
             const uint8_t* in = frame + e.src_off;
             const uint32_t lim = csz < 512u ? csz - 16u : 496u;
-            uint32_t pos = 0;
+            uint32_t pos = 0, first_end = 0;
             while (pos < lim && seqs < 256u) {                           // (lengths only; a malformed payload just gives a number)
                 const uint32_t t = in[pos++];
                 uint32_t lit = t >> 4;
@@ -672,8 +673,9 @@ __global__ __launch_bounds__(64) void k_density_probe(const uint8_t* __restrict_
                 pos += lit + 2;
                 if ((t & 15u) == 15u) { uint32_t x; do { x = pos < lim ? in[pos] : 0u; pos++; } while (x == 255u && pos < lim); }
                 seqs++;
+                if (seqs == 1) first_end = pos;
             }
-            bytes = pos < 1024u ? pos : 1024u;
+            if (seqs > 1) { seqs -= 1; bytes = (pos < 1024u ? pos : 1024u) - (first_end < pos ? first_end : pos); } else { seqs = 0; bytes = 0; }
         }
     }
     uint32_t st = seqs, bt = bytes;
