@@ -50,7 +50,8 @@ def build(force: bool = False) -> str:
 def lib():
     global _LIB
     if _LIB is None:
-        L = ctypes.CDLL(build())
+        # ORC_LIB: another build of the same sources (tests/test_oracle_sanitizers.py points it at the ASan/UBSan one)
+        L = ctypes.CDLL(os.environ.get("ORC_LIB") or build())
         vp, u8p = ctypes.c_void_p, ctypes.c_char_p
         sig = {
             "orc_xxh32": (ctypes.c_uint32, [vp, c_size_t, ctypes.c_uint32]),
