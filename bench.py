@@ -117,9 +117,32 @@ def main():
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
     args = ap.parse_args()
 
+    # N > 1 and not yet under a launcher: start N ranks (one process per GPU) as a CHILD process and relay its output - nothing in
+    # this process has touched the GPU yet (torch is not even imported).  Under a launcher WORLD_SIZE must be what --gpus says.
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            import socket
+            import torch                              # (counting devices does not initialise the GPU; the ranks are children of this process)
+            if torch.cuda.device_count() < args.gpus:
+                sys.exit("bench.py: --gpus %d but %d GPU(s) are visible: one process per GPU, no oversubscription" % (args.gpus, torch.cuda.device_count()))
+            with socket.socket() as s_:
+                s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
+            env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("MASTER_ADDR", "127.0.0.1")
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            sys.exit(subprocess.run(cmd, env=env).returncode)
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
+
     import numpy as np
     import torch
     import torch.distributed as dist
+
+    have = torch.cuda.device_count()              # (counting does not initialise the GPU)
+    if have < args.gpus:
+        sys.exit("bench.py: --gpus %d but %d GPU(s) are visible: one process per GPU, no oversubscription" % (args.gpus, have))
 
     from lz4_frame_conduit_amd import _ffi, conduit, datagen, shard
     from lz4_frame_conduit_amd.device import Engine, synth50_device
@@ -352,7 +375,11 @@ def main():
                                        "bare LZ4 frame: size-word walk + generic decoder" if args.foreign else
                                        "the compressor's index travels in the stream as a skippable frame behind the LZ4 frame; no block table, no side buffer"),
                        "bytes_per_gpu": n, "block_size": bs, "n_blocks_per_gpu": nb, "generator": "synth50 recipe, torch Philox seed 1234+rank",
-                       "sharding": "one 4 GiB stream per rank, no collective" if world > 1 else "single GPU"},
+                       "sharding": ("BASELINE configs[3] shape: %d ranks x %.0f GiB = %.0f GiB of synth50 per step, every rank its own stream (seed 1234+rank) of %d "
+                                    "independent blocks on its own GPU and HIP stream; nothing crosses ranks on the data path (no RCCL collective: blocks of an "
+                                    "independent-block frame need nothing from each other, SURVEY 8e); RCCL carries the barrier and the max-over-ranks time only"
+                                    % (world, n / GIB, world * n / GIB, nb)) if world > 1 else "single GPU",
+                       "rccl_ranks": (dist.get_world_size() if world > 1 else 1)},
             "ratio": round(n / frame_only, 4), "compressed_bytes": frame_only, "stream_bytes_with_trailer": csize_stream, "roundtrip_verified": ok,
             "compress_GiBs_per_gpu": round(n / (t_comp * 1e-3) / GIB, 2) if t_comp else None,
             "decompress_GiBs_per_gpu": round(n / (t_dec * 1e-3) / GIB, 2) if t_dec else None,

@@ -181,7 +181,8 @@ LZ4F_MI355X_API size_t lz4f_mi355x_decompressFrameTo(lz4f_mi355x_yield_fn yield,
                                                      size_t* srcConsumed);
 /* How many GPUs the bulk calls above deal their slabs over (round-robin, starting at the calling thread's device; default 1).
  * Blocks of an independent-block frame need nothing from each other: no collective, the host puts the slabs' output in order.
- * Process-wide. */
+ * Process-wide.  count must be <= the visible devices (test switch: with LZ4F_MI355X_LOGICAL_DEVICES=n in the environment up to
+ * n "logical" devices are accepted and mapped onto the visible ones, d mod visible - the dealing code runs as on n GPUs). */
 LZ4F_MI355X_API size_t lz4f_mi355x_use_devices(int count);
 /* Page-locked host memory for the bulk calls' src / dst (what the batched conduits gather their chunks in). */
 LZ4F_MI355X_API void*  lz4f_mi355x_host_alloc(size_t size);
@@ -270,7 +271,7 @@ LZ4F_MI355X_API size_t lz4f_mi355x_dev_index_size(size_t srcSize, const LZ4F_pre
  * and the list of the blocks' positions travel in the byte stream itself, as a skippable frame (magic 0x184D2A5E) right behind
  * the LZ4 frame: result.size includes it, d_dst must be 16-byte aligned and hold compressFrameBound + trailer_bound bytes.
  * liblz4, the `lz4` tool and the reference's `decompress` (Conduit.hsc:598: it stops at the EndMark) decode such a stream to the
- * same bytes; lz4f_mi355x_dev_decompressFrame finds the trailer from the stream's last 16 bytes and, after checking it against
+ * same bytes; lz4f_mi355x_dev_decompressFrame finds the trailer from the stream's last 32 bytes and, after checking it against
  * the frame itself, skips the walk over the size words and parses with the index. */
 #define LZ4F_MI355X_INBAND ((size_t)-1)
 /* result.flags: bits 0..7 the frame's FLG byte, bit 8 a skippable frame was skipped; bits 12.. say which way a decompress call

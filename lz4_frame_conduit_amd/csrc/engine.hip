@@ -164,7 +164,7 @@ lz4f_mi355x_engine::~lz4f_mi355x_engine()
     (void)hipSetDevice(device);
     (void)hipStreamSynchronize((hipStream_t)stream);
     desc.release(); seqcnt.release(); selfix.release(); selfcnt.release(); postab.release(); pdbuf.release();
-    info.release(); recs.release(); e1_scratch.release(); walkbuf.release(); ixtmp.release(); table.release(); blk_bytes.release(); res.release(); bad.release();
+    info.release(); recs.release(); e1_scratch.release(); walkbuf.release(); density.release(); ixtmp.release(); table.release(); blk_bytes.release(); res.release(); bad.release();
     d_in.release(); d_out.release();
     h_in.release(); h_out.release(); h_small.release();
     for (int i = 0; i < 20; i++) if (ev[i]) (void)hipEventDestroy((hipEvent_t)ev[i]);
@@ -207,6 +207,7 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
 {    // in-band: the index is made in the engine's own buffer and copied, with the block list, into a skippable frame behind the
     // LZ4 frame (frame_dev.cuh: the trailer)
     const bool inband = d_index == nullptr && index_cap == LZ4F_MI355X_INBAND;
+    HIP_TRY(hipSetDevice(device));                     // (before anything is allocated: the caller's current device may be another one)
     if (inband) {
         const size_t bsz = j.block_size, nb_ = (size_t)((j.src_size - j.first_off + bsz - 1) / bsz);
         const uint32_t ch_ = pick_chunk_size(j.block_size);
@@ -216,7 +217,6 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
         if (((uintptr_t)d_dst & 15) != 0) { set_last_error("in-band index: the frame buffer must be 16-byte aligned"); return make_err(LZ4F_ERROR_GENERIC); }
     }
 
-    HIP_TRY(hipSetDevice(device));
     hipStream_t st = (hipStream_t)stream;
     EncGeom g;
     memset(&g, 0, sizeof(g));

@@ -147,6 +147,7 @@ bool   is_pinned_host(const void* p);
 // pipelined bulk paths (pipeline.hip)
 int    bulk_devices();
 void   set_bulk_devices(int n);
+int    logical_devices();             // visible devices, or LZ4F_MI355X_LOGICAL_DEVICES when that is larger (test switch, pipeline.hip)
 // hist_before: valid input bytes in front of src (a linked frame's blocks reach 64 KiB back)
 size_t pipe_compress_blocks(const uint8_t* src, size_t n, uint32_t block_size, bool linked, bool bck, uint8_t* dst, size_t cap, size_t* written,
                             size_t hist_before = 0);

@@ -621,7 +621,7 @@ __global__ void k_trailer_plan(uint8_t* __restrict__ dst, uint64_t dst_cap, Resu
             TrailerFoot f{with_ix ? hd->total_seqs : 0u, with_ix ? hd->total_entries : 0u, 0u, 0u, TR_FOOT, n_blocks, p.total};
             memcpy(dst + p.ix_at + p.ix_bytes, &f, sizeof(f));
             res->size = F + p.total;
-        }
+        } else res->status = ST_DSTSMALL;        // the caller asked for the trailer (LZ4F_MI355X_INBAND) and it does not fit: say so instead of leaving it out
     }
     *plan = p;
 }

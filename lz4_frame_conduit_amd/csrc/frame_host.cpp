@@ -737,7 +737,7 @@ size_t lz4f_mi355x_decompressFrameTo(lz4f_mi355x_yield_fn yield, void* user, con
 
 size_t lz4f_mi355x_use_devices(int count)
 {
-    const int have = lz4f_mi355x_device_count();
+    const int have = logical_devices();       // (the visible ones; more only under the test switch LZ4F_MI355X_LOGICAL_DEVICES)
     if (count < 1 || count > have) { set_last_error("use_devices(%d): %d devices are visible", count, have); return make_err(LZ4F_ERROR_GENERIC); }
     set_bulk_devices(count);
     return 0;

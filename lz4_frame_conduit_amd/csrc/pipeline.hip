@@ -36,6 +36,18 @@ namespace lz4f {
 static std::atomic<int> g_devices{1};
 int bulk_devices() { return g_devices.load(); }
 void set_bulk_devices(int n) { g_devices.store(n < 1 ? 1 : n); }
+// LZ4F_MI355X_LOGICAL_DEVICES=n (test switch): lz4f_mi355x_use_devices() may then ask for up to n devices although fewer are
+// visible; logical device d is physical device d mod visible.  Everything above the engines - the deal of the slabs over the
+// devices, the turn order, one engine set per (logical) device - runs as it would on n GPUs; the link tokens are per PHYSICAL
+// device, as the link is.  It is how the multi-device code is exercised on a one-GPU box; it buys no speed.
+int logical_devices()
+{
+    int have = 0;
+    if (hipGetDeviceCount(&have) != hipSuccess || have < 0) { (void)hipGetLastError(); have = 0; }
+    if (have <= 0) return 0;
+    if (const char* v = getenv("LZ4F_MI355X_LOGICAL_DEVICES")) { const int n = atoi(v); if (n > have && n <= 64) return n; }
+    return have;
+}
 
 namespace {
 
@@ -58,7 +70,8 @@ struct Slots {
         const int first = selected_device();
         int have = 0;
         if (hipGetDeviceCount(&have) != hipSuccess || have <= 0) { set_last_error("no usable HIP device: liblz4f_mi355x has no CPU fallback"); return make_err(LZ4F_ERROR_GENERIC); }
-        if (ndev > have) ndev = have;
+        const int logical = logical_devices();
+        if (ndev > logical) ndev = logical;
         eng.resize((size_t)ndev * per_dev);
         for (int e = 0; e < per_dev; e++)
             for (int d = 0; d < ndev; d++) {                       // (slot order: device-major inside a round, so consecutive slabs go to different devices)

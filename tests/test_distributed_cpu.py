@@ -92,11 +92,12 @@ def _hip_worker(rank: int, world: int, port: int, outq):
         data = datagen.synth50(64 << 20, 99)
         n_blocks = len(data) // bs
         lo, hi = shard.contiguous_blocks(n_blocks, rank, world)
-        torch.cuda.set_device(rank)
-        eng = Engine(rank)
+        dev_i = rank % torch.cuda.device_count()                         # (a one-GPU box: both ranks on device 0, still one process per rank)
+        torch.cuda.set_device(dev_i)
+        eng = Engine(dev_i)
         prefs = conduit.make_preferences(blockSizeID=7, blockMode=1)
-        src = torch.from_numpy(data[lo * bs:hi * bs].copy()).cuda(rank)
-        frame = torch.empty(eng.frame_bound(src.numel(), prefs), dtype=torch.uint8, device="cuda:%d" % rank)
+        src = torch.from_numpy(data[lo * bs:hi * bs].copy()).cuda(dev_i)
+        frame = torch.empty(eng.frame_bound(src.numel(), prefs), dtype=torch.uint8, device="cuda:%d" % dev_i)
         eng.compress_async(src, frame, prefs)
         r = eng.result()
         body = frame[7:r.size - 4].cpu().numpy().tobytes()              # without the 7-byte header and the EndMark
@@ -109,8 +110,8 @@ def _hip_worker(rank: int, world: int, port: int, outq):
             whole = oracle.header_bytes(oracle.mkprefs(bsid=7, indep=1)) + b"".join(gathered) + bytes(4)
             out, used = oracle.decompress_frame(whole, cap=len(data) + 64)
             assert used == len(whole) and out == data.tobytes()
-            dev = torch.from_numpy(np.frombuffer(whole, dtype=np.uint8).copy()).cuda(0)
-            back = torch.zeros(len(data), dtype=torch.uint8, device="cuda:0")
+            dev = torch.from_numpy(np.frombuffer(whole, dtype=np.uint8).copy()).cuda(dev_i)
+            back = torch.zeros(len(data), dtype=torch.uint8, device="cuda:%d" % dev_i)
             eng.decompress_frame_async(dev, dev.numel(), back)
             r2 = eng.result()
             assert r2.size == len(data) and back.cpu().numpy().tobytes() == data.tobytes()
@@ -125,9 +126,9 @@ def _hip_worker(rank: int, world: int, port: int, outq):
 
 @pytest.mark.gpu
 def test_contiguous_runs_world2_hip_path():
-    """The same sharding with the HIP codec on two GPUs (skipped where fewer than two are visible - the round-end GPU box has one)."""
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs two GPUs")
+    """The same sharding with the HIP codec, one process per rank: rank r on GPU r where two are visible, both ranks on the one GPU
+    of a one-GPU box (two processes, two HIP contexts, gloo for the sizes)."""
+    assert torch.cuda.device_count() >= 1
     import oracle
     oracle.build()
     ctx = mp.get_context("spawn")
@@ -140,3 +141,19 @@ def test_contiguous_runs_world2_hip_path():
     for p in procs:
         p.join(60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def test_bench_gpus_flag_is_honoured():
+    """`bench.py --gpus N` must never be a silent 1-GPU run: without a launcher it starts N ranks itself (one child process per GPU)
+    and refuses when fewer than N GPUs are visible; under a launcher WORLD_SIZE has to agree with --gpus."""
+    import subprocess
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    n = torch.cuda.device_count() + 1
+    if n < 2: n = 2
+    r = subprocess.run([sys.executable, bench, "--gpus", str(n)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr, (r.returncode, r.stderr[-400:])
+    assert "\"metric\"" not in r.stdout
+    env["WORLD_SIZE"] = "3"
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr, (r.returncode, r.stderr[-400:])

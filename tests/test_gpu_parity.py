@@ -3,6 +3,8 @@ vectors.  Bar: bit-exact decode; encode round-trips bit-e
 ratio stays within the stated tolerance of LZ4_compress_default (the oracle is bit-exact with it)."""
 import ctypes
 import hashlib
+import os
+import sys
 
 import numpy as np
 import pytest
@@ -16,6 +18,7 @@ pytestmark = pytest.mark.gpu
 # encoder ratio tolerance vs LZ4_compress_default: compressed size may exceed liblz4's by at most this factor
 RATIO_TOL = 1.05
 sha = lambda b: hashlib.sha256(b).hexdigest()
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -1012,25 +1015,42 @@ def test_device_path_content_checksum(L):
 
 
 @pytest.mark.gpu
-def test_bulk_calls_over_several_gpus(L):
+def test_bulk_calls_over_several_gpus():
     """lz4f_mi355x_use_devices: the host-pointer bulk calls deal their slabs over that many GPUs (blocks of an independent-block
-    frame need nothing from each other: no collective, the host puts the output in order).  With one GPU visible only the
-    argument checks run; with two or more the round trip goes over two and must give liblz4-decodable frames and the input back."""
-    import torch
-    have = torch.cuda.device_count()
-    assert L.lz4f_mi355x_device_count() == have
-    assert L.LZ4F_isError(L.lz4f_mi355x_use_devices(0)) and L.LZ4F_isError(L.lz4f_mi355x_use_devices(have + 1))
-    assert L.lz4f_mi355x_use_devices(1) == 0
-    if have < 2:
-        pytest.skip("one GPU visible: the two-GPU round trip needs two")
-    data = datagen.synth50(300 << 20, 41).tobytes()
-    try:
-        assert L.lz4f_mi355x_use_devices(2) == 0
-        for kw in (dict(bsid=7, indep=1), dict(bsid=4, indep=1, bck=1), dict(bsid=4, indep=0)):
-            frame = gpu_compress_frame(L, data, prefs_of(kw))
-            out, used = oracle.decompress_frame(frame, cap=len(data) + 64)
-            assert used == len(frame) and out == data, kw
-            back, used2 = gpu_decompress_frame(L, frame, len(data) + 8)
-            assert used2 == len(frame) and back == data, kw
-    finally:
-        L.lz4f_mi355x_use_devices(1)
+    frame need nothing from each other: no collective, the host puts the output in order).  Runs in a child process with
+    LZ4F_MI355X_LOGICAL_DEVICES=3, so that on a one-GPU box the deal over devices, the turn order of the slabs and the engine sets
+    per device run exactly as they would on three GPUs (logical device d = physical d mod visible); with several GPUs visible the
+    same code spreads over them.  liblz4 (the oracle) must decode the frames, the library must give the input back."""
+    import subprocess
+    code = r"""
+import sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+import oracle
+from lz4_frame_conduit_amd import _ffi, datagen
+sys.path.insert(0, %r)
+from test_gpu_parity import gpu_compress_frame, gpu_decompress_frame, prefs_of
+L = _ffi.lib()
+have = torch.cuda.device_count()
+assert L.lz4f_mi355x_device_count() == have >= 1
+n = max(3, have)
+assert L.LZ4F_isError(L.lz4f_mi355x_use_devices(0)) and L.LZ4F_isError(L.lz4f_mi355x_use_devices(n + 1))
+assert L.lz4f_mi355x_use_devices(1) == 0
+data = datagen.synth50(300 << 20, 41).tobytes()
+one = {}
+for devs in (1, n, 2):
+    assert L.lz4f_mi355x_use_devices(devs) == 0
+    for kw in (dict(bsid=7, indep=1), dict(bsid=4, indep=1, bck=1), dict(bsid=4, indep=0)):
+        frame = gpu_compress_frame(L, data, prefs_of(kw))
+        out, used = oracle.decompress_frame(frame, cap=len(data) + 64)
+        assert used == len(frame) and out == data, (devs, kw)
+        back, used2 = gpu_decompress_frame(L, frame, len(data) + 8)
+        assert used2 == len(frame) and back == data, (devs, kw)
+        one.setdefault(str(kw), len(frame))
+        assert abs(len(frame) - one[str(kw)]) <= one[str(kw)] // 200, (devs, kw, len(frame), one[str(kw)])      # (same slabs, same blocks: the size can only differ by the encoder's races)
+L.lz4f_mi355x_use_devices(1)
+print("ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ); env["LZ4F_MI355X_LOGICAL_DEVICES"] = "3"
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.returncode, r.stdout[-300:], r.stderr[-1500:])
