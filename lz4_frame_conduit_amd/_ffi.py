@@ -10,6 +10,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblz4f_mi355x.so")
+if os.environ.get("LZ4F_MI355X_LIB"):         # development: a variant build of the same library (tools/ab_build.sh), for A-B measurements
+    LIB_PATH = os.environ["LZ4F_MI355X_LIB"]
 
 c_size_t, c_void_p = ctypes.c_size_t, ctypes.c_void_p
 
