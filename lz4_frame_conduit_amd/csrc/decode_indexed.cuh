@@ -73,48 +73,14 @@ __global__ void k_check_index(const void* __restrict__ ix, uint64_t ix_size, uin
     if (!ok) atomicOr(flags, 1u);
 }
 
-// k_parse_indexed, one lane per index entry.  (The index structures and k_build_index live in encode.cuh: pass E2 writes the entries.)
-// Input-side rules only (the feeder wave checks the ones that need output positions).  `flags[0]` is set when anything
-// disagrees with the index: the caller then falls back to the generic decoder.  Every entry must end exactly where the next
-// one starts and the first one of a block at payload byte 0, so the descriptors are a complete parse of the payload itself:
-// a wrong index can make the call fall back, never change the bytes that come out.
-__device__ __forceinline__ void parse_entry(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
-                                            const void* __restrict__ ix, uint32_t n_blocks, uint32_t n_entries,
-                                            SeqDesc* __restrict__ desc, uint64_t desc_cap, uint32_t* __restrict__ flags, uint32_t gid, uint32_t linked, uint64_t hist0)
+// `my_nseq` sequences of the payload in[0, csize) from `pos` on (output position `op`): their descriptors -> out[0 .. my_nseq).
+// Input-side rules only.  Returns true when something is wrong; `pos` is left where the walk ended (the caller checks that it
+// is where the next run starts).  `is_tail`: the run holds the block's last sequence.  `out_front`: output bytes in front of the
+// block that a match of a linked frame may reach.
+__device__ __forceinline__ bool parse_run(const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable, uint32_t& pos, uint32_t op, uint32_t my_nseq,
+                                          bool is_tail, SeqDesc* __restrict__ out, uint32_t linked, uint64_t out_front)
 {
-    const IxBlock* blocks = ix_blocks(ix);
-    if (gid < n_blocks) {
-        // the block table must hand out the descriptors and the entries without gaps or overlaps (every descriptor is then
-        // written by exactly one lane), and a compressed block without entries cannot be decoded from the index
-        const IxBlock bk = blocks[gid];
-        const bool stored = (table[gid].word >> 31) != 0;
-        bool wrong = stored ? (bk.nentries != 0 || bk.nseq != 0) : (bk.nentries == 0 || bk.nseq == 0);
-        if (gid == 0) wrong |= bk.seq_base != 0 || bk.entry_base != 0;
-        const uint64_t seq_end = (uint64_t)bk.seq_base + bk.nseq, ent_end = (uint64_t)bk.entry_base + bk.nentries;
-        if (gid + 1 < n_blocks) wrong |= blocks[gid + 1].seq_base != seq_end || blocks[gid + 1].entry_base != ent_end;
-        else wrong |= seq_end != desc_cap || ent_end != n_entries;
-        if (wrong) atomicOr(flags, 1u);
-    }
-    if (gid >= n_entries) return;
-    const IxEntry* entries = ix_entries(ix, n_blocks);
-    const IxEntry me = entries[gid];
-    const uint32_t b = me.nseq_blk >> 8, my_nseq = me.nseq_blk & 0xFFu;
-    if (b >= n_blocks) { atomicOr(flags, 1u); return; }
-    const IxBlock blk = blocks[b];
-    const BlockOut e = table[b];
-    const uint32_t csize = e.word & 0x7FFFFFFFu;
-    bool bad = (e.word >> 31) != 0 || e.src_off + csize > frame_cap || me.in_off >= csize || my_nseq == 0 || gid < blk.entry_base ||
-               gid >= blk.entry_base + blk.nentries || (uint64_t)me.seq_off + my_nseq > blk.nseq || (uint64_t)blk.seq_base + blk.nseq > desc_cap;
-    if (bad) { atomicOr(flags, 1u); return; }
-    const bool is_head = gid == blk.entry_base, is_tail = gid + 1 == blk.entry_base + blk.nentries;
-    const uint32_t stop = is_tail ? csize : entries[gid + 1].in_off;           // where the next entry of this block starts (or the payload ends)
-    if (is_head && (me.in_off != 0 || me.out_pos != 0 || me.seq_off != 0)) bad = true;      // the entries must cover the payload from its first byte
-    if (!is_tail && entries[gid + 1].seq_off != me.seq_off + my_nseq) bad = true;
-    if (is_tail && me.seq_off + my_nseq != blk.nseq) bad = true;
-    const uint8_t* in = frame + e.src_off;
-    const uint64_t readable = frame_cap - e.src_off;
-    SeqDesc* out = desc + blk.seq_base + me.seq_off;
-    uint32_t pos = me.in_off, op = me.out_pos;
+    bool bad = false;
     // the last four output ranges whose bytes are known to sit in the payload (literal runs, and matches that copied from such a
     // range): a match that lies inside one is DIRECT -- a plain copy out of the payload that needs no earlier output
     uint32_t r0o = 0, r0n = 0, r0p = 0, r1o = 0, r1n = 0, r1p = 0, r2o = 0, r2n = 0, r2p = 0, r3o = 0, r3n = 0, r3p = 0;
@@ -167,7 +133,7 @@ __device__ __forceinline__ void parse_entry(const uint8_t* __restrict__ frame, u
         if (mlen) {
             const uint32_t dm = op + lit;
             // a source in front of the block: only in a linked frame, and only as far as there is output before this block
-            if (off > dm && (!linked || (uint64_t)(off - dm) > e.dst_off + hist0)) { bad = true; break; }      // (hist0: output of an earlier call in front of this frame part)
+            if (off > dm && (!linked || (uint64_t)(off - dm) > out_front)) { bad = true; break; }      // (hist0: output of an earlier call in front of this frame part)
             const uint32_t s0 = dm - off;
             uint32_t msrc = 0xFFFFFFFFu;
             if (mlen <= off && off <= dm) {
@@ -181,6 +147,52 @@ __device__ __forceinline__ void parse_entry(const uint8_t* __restrict__ frame, u
         out[i] = SeqDesc{p | ((f24 & 0xFFu) << 24), lit | (((f24 >> 8) & 0xFFu) << 24), op, mw | (((f24 >> 16) & 0x7Fu) << 24)};
         op += lit + mlen;
     }
+    return bad;
+}
+
+// k_parse_indexed, one lane per index entry.  (The index structures and k_build_index live in encode.cuh: pass E2 writes the entries.)
+// Input-side rules only (the feeder wave checks the ones that need output positions).  `flags[0]` is set when anything
+// disagrees with the index: the caller then falls back to the generic decoder.  Every entry must end exactly where the next
+// one starts and the first one of a block at payload byte 0, so the descriptors are a complete parse of the payload itself:
+// a wrong index can make the call fall back, never change the bytes that come out.
+__device__ __forceinline__ void parse_entry(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
+                                            const void* __restrict__ ix, uint32_t n_blocks, uint32_t n_entries,
+                                            SeqDesc* __restrict__ desc, uint64_t desc_cap, uint32_t* __restrict__ flags, uint32_t gid, uint32_t linked, uint64_t hist0)
+{
+    const IxBlock* blocks = ix_blocks(ix);
+    if (gid < n_blocks) {
+        // the block table must hand out the descriptors and the entries without gaps or overlaps (every descriptor is then
+        // written by exactly one lane), and a compressed block without entries cannot be decoded from the index
+        const IxBlock bk = blocks[gid];
+        const bool stored = (table[gid].word >> 31) != 0;
+        bool wrong = stored ? (bk.nentries != 0 || bk.nseq != 0) : (bk.nentries == 0 || bk.nseq == 0);
+        if (gid == 0) wrong |= bk.seq_base != 0 || bk.entry_base != 0;
+        const uint64_t seq_end = (uint64_t)bk.seq_base + bk.nseq, ent_end = (uint64_t)bk.entry_base + bk.nentries;
+        if (gid + 1 < n_blocks) wrong |= blocks[gid + 1].seq_base != seq_end || blocks[gid + 1].entry_base != ent_end;
+        else wrong |= seq_end != desc_cap || ent_end != n_entries;
+        if (wrong) atomicOr(flags, 1u);
+    }
+    if (gid >= n_entries) return;
+    const IxEntry* entries = ix_entries(ix, n_blocks);
+    const IxEntry me = entries[gid];
+    const uint32_t b = me.nseq_blk >> 8, my_nseq = me.nseq_blk & 0xFFu;
+    if (b >= n_blocks) { atomicOr(flags, 1u); return; }
+    const IxBlock blk = blocks[b];
+    const BlockOut e = table[b];
+    const uint32_t csize = e.word & 0x7FFFFFFFu;
+    bool bad = (e.word >> 31) != 0 || e.src_off + csize > frame_cap || me.in_off >= csize || my_nseq == 0 || gid < blk.entry_base ||
+               gid >= blk.entry_base + blk.nentries || (uint64_t)me.seq_off + my_nseq > blk.nseq || (uint64_t)blk.seq_base + blk.nseq > desc_cap;
+    if (bad) { atomicOr(flags, 1u); return; }
+    const bool is_head = gid == blk.entry_base, is_tail = gid + 1 == blk.entry_base + blk.nentries;
+    const uint32_t stop = is_tail ? csize : entries[gid + 1].in_off;           // where the next entry of this block starts (or the payload ends)
+    if (is_head && (me.in_off != 0 || me.out_pos != 0 || me.seq_off != 0)) bad = true;      // the entries must cover the payload from its first byte
+    if (!is_tail && entries[gid + 1].seq_off != me.seq_off + my_nseq) bad = true;
+    if (is_tail && me.seq_off + my_nseq != blk.nseq) bad = true;
+    const uint8_t* in = frame + e.src_off;
+    const uint64_t readable = frame_cap - e.src_off;
+    SeqDesc* out = desc + blk.seq_base + me.seq_off;
+    uint32_t pos = me.in_off;
+    if (!bad) bad = parse_run(in, csize, readable, pos, me.out_pos, my_nseq, is_tail, out, linked, e.dst_off + hist0);
     if (!bad && pos != stop) bad = true;                                       // must end exactly where the next entry starts
     if (bad) atomicOr(flags, 1u);
 }
@@ -376,11 +388,13 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_selfindex_walk_wave(const
 // and every block's place in the output.  flags[8] / flags[9] get the totals (the host reads them to size the workspaces).
 __global__ __launch_bounds__(1024) void k_selfindex_scan(BlockOut* __restrict__ table, const ResultRec* __restrict__ res, uint32_t n_max,
                                                          const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ osz, void* __restrict__ ix,
-                                                         uint32_t chunks_per_block, uint64_t dst_cap, uint32_t block_size, uint32_t* __restrict__ flags)
+                                                         uint32_t chunks_per_block, uint64_t dst_cap, uint32_t block_size, uint32_t* __restrict__ flags,
+                                                         uint32_t strict = 0)
 {
     __shared__ uint64_t s_a[1024], s_b[1024], s_c[1024];
     __shared__ uint64_t c_a, c_b, c_c;
     if (res->status != ST_OK) return;
+    if (strict && *flags) return;                                        // (independent blocks: the table stays what the generic decoder needs)
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
     const uint32_t t = threadIdx.x;
     IxBlock* blocks = ix_blocks(ix);

@@ -1,0 +1,232 @@
+// decode_spx.cuh -- foreign frames of BIG INDEPENDENT blocks (what `lz4 -c` and liblz4's LZ4F_compressFrame write by default with
+// -B7: the frames the reference's decompress tests feed, /root/reference/test/Main.hs:33-36) onto the indexed kernels
+// (SURVEY.md section 8a rows a3/a4).
+//
+// Such a frame brings no index, and the parse of a 4 MiB block is one dependent chain: 4 k sequences at 1280 cycles each on the
+// fused decoder's scalar parser (2.3 ms per block, decode_fused.cuh), ~10 ms for a lane at memory latency (k_selfindex_walk).
+// Here the chain is cut:
+//   k_spx_index   a workgroup per block, a LANE per 32 KiB segment of the payload.  Lane u starts at a GUESS - it knows no token
+//                 position in its segment - and follows the sequences from there to where lane u + 1 starts.  A chain that starts
+//                 at a wrong byte is garbage, but a chain is a function of its position: lane 0 starts at byte 0 and is true, and
+//                 lane u + 1 is true iff the (true) chain in front of it lands EXACTLY on its start.  One thread stitches: it
+//                 follows the landings from lane to lane; where the true chain does not land on the next lane's start (a wrong
+//                 guess) it walks on itself, from where the chain stands, until it meets a later lane's start.  Equality of
+//                 positions is the whole proof, so a wrong guess can cost time, never change the result.
+//                 Guessing well is what makes lanes meet.  Long literal runs (the payloads where a guessed chain would need ~20 KiB
+//                 to fall into step: it hops ~15 bytes at a time through 500 random bytes) announce themselves: a token with
+//                 literal length >= 270 is a byte 0xF? followed by 0xFF - one position in 4096 of random bytes.  A lane scans the
+//                 first 4 KiB of its segment for such a pair whose sequence leads to another one, and starts there (bench frame:
+//                 1-2 of 68 000 lanes guess wrong).  Without such a pair it starts at its segment's first byte; payloads of short
+//                 sequences are the dense ones, which do not come here (k_density_probe).
+//                 Result per block: the sequence count, the output size, and a true (position, sequence number, output position)
+//                 at the start of every stretch.
+//   k_spx_parse   a lane per stretch: the sequences of that stretch -> descriptors, with parse_run()
+//                 - the code k_parse_indexed runs per index entry, same rules, same direct-match marking.  Every stretch must end
+//                 exactly where the next one starts, the last at the payload's end with the block's last sequence.
+// Behind them k_resolve_direct and k_copy_indexed run as for a frame that came with the compressor's index.  Anything odd - a
+// malformed payload, short blocks inside the frame, a stretch that does not end where it should - sets flags[0], and the generic
+// decoder launched behind decodes the frame and gives the verdict.
+#pragma once
+#include "decode_indexed.cuh"
+
+namespace lz4f {
+
+constexpr uint32_t SPX_SEG = 32768, SPX_SCAN = 4096, SPX_MAXSEG = (4u << 20) / SPX_SEG;      // lanes per block <= 128
+constexpr uint32_t SPX_RESCUE = 1u << 16;                       // sequences the stitching thread may walk itself per block before it gives up
+constexpr uint32_t SPX_NONE = 0xFFFFFFFFu;
+struct SpxPoint { uint32_t pos, seq, out; };                    // a token position of the block's payload, the number of the sequence that starts there, its output position
+
+// One sequence of the payload in[0, csize) at c.pos: lengths only (the walk that finds out WHERE sequences are; parse_run checks
+// what they say).  Returns 0: went on to the next token; 1: that was the block's last sequence (c.pos = csize); 2: not a sequence
+// this payload can hold.  One dependent 16-byte load per sequence (the word at the match offset holds the next token as well).
+struct SpxCur { uint32_t pos, seq, out; uint64_t w, w_hi; };
+__device__ __forceinline__ void spx_begin(const uint8_t* __restrict__ in, uint64_t readable, SpxCur& c) { pt_load16(in, c.pos, readable, c.w, c.w_hi); }
+__device__ __forceinline__ int spx_step(const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable, SpxCur& c)
+{
+    if (c.pos >= csize) return 2;
+    const uint32_t token = (uint32_t)c.w & 0xFF;
+    uint32_t lit = token >> 4, p = c.pos + 1;
+    if (lit == 15) {
+        const uint64_t x = c.w >> 8;
+        const uint32_t f = (uint32_t)__builtin_ctzll(~x), kk = f >> 3;
+        if (kk < 7) { lit += 255u * kk + (uint32_t)((x >> (f & 56u)) & 0xFF); p += kk + 1; }
+        else { for (;;) { if (p >= csize || lit > (1u << 24)) return 2; const uint32_t v = in[p++]; lit += v; if (v != 255) break; } }
+    }
+    if (p > csize || lit >= (1u << 24)) return 2;
+    const uint32_t in_left = csize - p;
+    c.seq++;
+    if (lit + 8 > in_left) { if (lit != in_left) return 2; c.out += lit; c.pos = csize; return 1; }
+    const uint32_t q = p + lit;
+    uint64_t w2, w2_hi;
+    pt_load16(in, q, readable, w2, w2_hi);
+    uint32_t mlen = token & 15, pn = q + 2;
+    bool reload = false;
+    if (mlen == 15) {
+        const uint64_t x = w2 >> 16;
+        const uint32_t f = (uint32_t)__builtin_ctzll(~x), kk = f >> 3;
+        if (kk < 6) { mlen += 255u * kk + (uint32_t)((x >> (f & 56u)) & 0xFF); pn += kk + 1; }
+        else { reload = true; for (;;) { if (pn >= csize || mlen > (1u << 24)) return 2; const uint32_t v = in[pn++]; mlen += v; if (v != 255) break; } }
+    }
+    c.out += lit + mlen + 4;
+    c.pos = pn;
+    if (c.out > (1u << 23)) return 2;
+    if (reload) pt_load16(in, c.pos, readable, c.w, c.w_hi);
+    else { const uint32_t sh = (pn - q) * 8u; c.w = sh >= 64 ? w2_hi : ((w2 >> sh) | (w2_hi << (64u - sh))); }
+    return 0;
+}
+
+// lanes of a block: lane 0 starts at byte 0; lane u >= 1 exists while the stretch it looks for its start in lies inside the payload with room behind it
+__device__ __forceinline__ uint32_t spx_lanes(uint32_t csize)
+{
+    if (csize <= SPX_SEG + SPX_SCAN + 64u) return 1u;
+    const uint32_t n = (csize - SPX_SCAN - 64u - 1u) / SPX_SEG + 1u;     // largest u with u * SEG + SCAN + 64 < csize, + 1
+    return n < SPX_MAXSEG ? n : SPX_MAXSEG;
+}
+
+// a likely token for a lane to start at: the first "0xF? 0xFF" pair in [from, from + SPX_SCAN) whose chain leads to another such pair
+// (or whose sequence is long enough to be no accident); `from` itself when there is none
+__device__ __forceinline__ uint32_t spx_guess(const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable, uint32_t from)
+{
+    const uint32_t lim = (from + SPX_SCAN + 24u < csize) ? from + SPX_SCAN : (csize > 24u ? csize - 24u : 0u);
+    uint32_t tries = 0;
+    for (uint32_t a = from; a < lim; a += 8) {
+        const uint64_t x = pt_load8(in, a, readable), y = pt_load8(in, a + 8, readable);      // (independent loads: the compiler keeps several in flight)
+        // byte i is 0xF?, byte i + 1 is 0xFF, for i = 0..7 (bit tricks that stay inside their byte)
+        const uint64_t nx = (x >> 8) | (y << 56);
+        uint64_t m = x & (x >> 2); m = m & (m >> 1) & 0x1010101010101010ull;                                  // bit 4 of byte i: its bits 4..7 are all set
+        uint64_t ff = nx & (nx >> 4); ff = ff & (ff >> 2); ff = ff & (ff >> 1) & 0x0101010101010101ull;      // bit 0 of byte i: byte i + 1 is 0xFF
+        uint64_t cand = (m >> 4) & ff;
+        while (cand && tries < 8) {
+            const uint32_t i = (uint32_t)__builtin_ctzll(cand) >> 3;
+            cand &= cand - 1;
+            tries++;
+            SpxCur c{a + i, 0, 0, 0, 0};
+            spx_begin(in, readable, c);
+            const int r = spx_step(in, csize, readable, c);
+            if (r == 1) return a + i;
+            if (r == 0 && c.pos + 2 < csize) {
+                const uint32_t t = (uint32_t)c.w & 0xFFFFu;
+                if ((t & 0xF0u) == 0xF0u && (t >> 8) == 0xFFu) return a + i;               // the next token announces a long literal run as well
+            }
+        }
+        if (tries >= 8) break;
+    }
+    return from;
+}
+
+// ---- k_spx_index: a workgroup per block ----
+// T (SPX_MAXSEG + 1 points per block): T[k] = where stretch k starts (k = 0: byte 0), T[stretches] = the payload's end; nr[b]: stretches.
+__global__ __launch_bounds__(128) void k_spx_index(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
+                                                   const ResultRec* __restrict__ res, uint32_t n_max, uint32_t* __restrict__ cnt, uint32_t* __restrict__ osz,
+                                                   SpxPoint* __restrict__ T, uint32_t* __restrict__ nr, uint32_t* __restrict__ flags,
+                                                   const uint32_t* __restrict__ only_if)
+{
+    __shared__ uint32_t s_g[SPX_MAXSEG + 1];                    // where lane u starts: its guess (lane 0: byte 0); [lanes]: SPX_NONE
+    __shared__ SpxPoint s_b[SPX_MAXSEG];                        // per lane: where its chain lands at or behind the NEXT lane's start (counts relative to its own start); pos SPX_NONE: nowhere
+    __shared__ uint32_t s_end[SPX_MAXSEG];                      // per lane: 1 = s_b is the payload's end (pos == csize: the counts include the last sequence)
+    if (res->status != ST_OK) return;
+    const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    const uint32_t b = blockIdx.x, u = threadIdx.x;
+    if (b >= n) return;
+    if (only_if && *only_if == 0) { if (u == 0) { cnt[b] = 0; osz[b] = 0; nr[b] = 0; atomicOr(flags, 1u); } return; }      // (dense payloads: not this path)
+    const BlockOut e = table[b];
+    const uint32_t csize = e.word & 0x7FFFFFFFu;
+    if (e.word >> 31) { if (u == 0) { cnt[b] = 0; osz[b] = csize; nr[b] = 0; } return; }
+    if (csize == 0 || e.src_off + csize > frame_cap) { if (u == 0) { atomicOr(flags, 1u); cnt[b] = 0; osz[b] = 0; nr[b] = 0; } return; }
+    const uint8_t* in = frame + e.src_off;
+    const uint64_t readable = frame_cap - e.src_off;
+    const uint32_t nl = spx_lanes(csize);
+    // ---- every lane's start: a guess (no overlap between lanes: lane u walks from its start to where lane u + 1 starts, and is
+    // ---- followed by a true lane iff it lands exactly there) ----
+    if (u < nl) s_g[u] = u ? spx_guess(in, csize, readable, u * SPX_SEG) : 0u;
+    if (u == nl) s_g[u] = SPX_NONE;
+    __syncthreads();
+    if (u < nl) {
+        const uint32_t stop = s_g[u + 1];                                   // (SPX_NONE for the last lane: it walks to the end)
+        SpxPoint pb{SPX_NONE, 0, 0};
+        uint32_t ended = 0;
+        SpxCur c{s_g[u], 0, 0, 0, 0};
+        spx_begin(in, readable, c);
+        for (;;) {
+            if (c.pos >= stop) { pb = SpxPoint{c.pos, c.seq, c.out}; break; }
+            const int r = spx_step(in, csize, readable, c);
+            if (r == 1) { pb = SpxPoint{c.pos, c.seq, c.out}; ended = 1; break; }      // the payload's end (for a guessed chain: what looks like it)
+            if (r == 2) break;                                               // (a guessed chain may run into anything)
+        }
+        s_b[u] = pb; s_end[u] = ended;
+    }
+    __syncthreads();
+    if (u != 0) return;
+    // ---- the stitch: lane 0 starts at byte 0 and is true; lane k + 1 is true iff the true chain lands exactly on its start.  A lane
+    // ---- that is not (a wrong guess) is skipped: the thread walks on from where the true chain stands until it meets a later lane's start.
+    SpxPoint* Tb = T + (size_t)b * (SPX_MAXSEG + 1);
+    uint32_t k = 0, rescue = 0, stretches = 0;
+    bool bad = false;
+    SpxPoint cur{0, 0, 0};                                                   // the true chain: where stretch `stretches` starts
+    uint32_t total_seq = 0, total_out = 0;
+    for (;;) {
+        // lane k starts where the true chain stands (cur.pos == s_g[k]): its walk is the true chain's
+        Tb[stretches++] = cur;
+        SpxPoint nx{SPX_NONE, 0, 0}; uint32_t ended = 0;
+        if (s_b[k].pos != SPX_NONE) { nx = SpxPoint{s_b[k].pos, cur.seq + s_b[k].seq, cur.out + s_b[k].out}; ended = s_end[k]; }
+        else { bad = true; break; }                                          // (a true chain that runs into something: malformed payload)
+        uint32_t kn = k + 1;
+        while (!ended && !(kn < nl && s_g[kn] == nx.pos)) {
+            // the true chain did not land on the next lane's start (or there is none): walk on from where it stands, to the start of
+            // the first lane it meets (or the end); that lane's own walk is the true chain again
+            if (kn < nl && s_g[kn] < nx.pos) { kn++; continue; }             // (that lane's start lies behind us already)
+            const uint32_t stop = kn < nl ? s_g[kn] : SPX_NONE;
+            atomicAdd(&flags[2], 1u);                                        // (how often: a developer's number, LZ4F_MI355X_PROF prints it)
+            SpxCur c{nx.pos, nx.seq, nx.out, 0, 0};
+            spx_begin(in, readable, c);
+            for (;;) {
+                if (c.pos >= stop) break;
+                if (++rescue > SPX_RESCUE) { bad = true; break; }
+                const int r = spx_step(in, csize, readable, c);
+                if (r == 1) { ended = 1; break; }
+                if (r == 2) { bad = true; break; }
+            }
+            if (bad) break;
+            nx = SpxPoint{c.pos, c.seq, c.out};
+        }
+        if (bad) break;
+        if (ended) {
+            if (nx.pos != csize) { bad = true; break; }
+            total_seq = nx.seq; total_out = nx.out; break;
+        }
+        k = kn; cur = nx;
+    }
+    if (bad || total_seq == 0) { atomicOr(flags, 1u); cnt[b] = 0; osz[b] = 0; nr[b] = 0; return; }
+    Tb[stretches] = SpxPoint{csize, total_seq, total_out};                   // the end, as the last stretch's stop
+    cnt[b] = total_seq; osz[b] = total_out; nr[b] = stretches;
+}
+
+// ---- k_spx_parse: a lane per stretch ----
+__global__ __launch_bounds__(128) void k_spx_parse(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
+                                                  const ResultRec* __restrict__ res, uint32_t n_max, const void* __restrict__ ix,
+                                                  const SpxPoint* __restrict__ T, const uint32_t* __restrict__ nr, SeqDesc* __restrict__ desc,
+                                                  uint32_t* __restrict__ flags)
+{
+    if (res->status != ST_OK || *flags) return;
+    const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    const uint32_t b = blockIdx.x;
+    if (b >= n) return;
+    const uint32_t stretches = nr[b];
+    const uint64_t desc_cap = flags[9];
+    const IxBlock blk = ix_blocks(ix)[b];
+    const BlockOut e = table[b];
+    const uint32_t csize = e.word & 0x7FFFFFFFu;
+    if (stretches && ((e.word >> 31) || e.src_off + csize > frame_cap || (uint64_t)blk.seq_base + blk.nseq > desc_cap)) { if (threadIdx.x == 0) atomicOr(flags, 1u); return; }
+    const SpxPoint* Tb = T + (size_t)b * (SPX_MAXSEG + 1);
+    for (uint32_t k = threadIdx.x; k < stretches; k += blockDim.x) {
+        const SpxPoint from = Tb[k], to = Tb[k + 1];
+        const bool is_tail = k + 1 == stretches;
+        bool bad = to.seq <= from.seq || to.seq > blk.nseq || (is_tail && (to.seq != blk.nseq || to.pos != csize)) || (k == 0 && (from.pos | from.seq | from.out) != 0);
+        uint32_t pos = from.pos;
+        if (!bad) bad = parse_run(frame + e.src_off, csize, frame_cap - e.src_off, pos, from.out, to.seq - from.seq, is_tail, desc + blk.seq_base + from.seq, 0u, 0ull);
+        if (!bad && pos != to.pos) bad = true;                                   // must end exactly where the next stretch starts
+        if (bad) atomicOr(flags, 1u);
+    }
+}
+
+}  // namespace lz4f

@@ -85,7 +85,7 @@ void lz4f_mi355x_engine::Switches::read()
     no_index = on("LZ4F_MI355X_NO_INDEX"); no_selfindex = on("LZ4F_MI355X_NO_SELFINDEX"); no_resolve = on("LZ4F_MI355X_NO_RESOLVE");
     no_trace = on("LZ4F_MI355X_NO_TRACE"); no_doubling = on("LZ4F_MI355X_NO_DOUBLING"); trace_always = on("LZ4F_MI355X_TRACE_ALWAYS");
     no_groups = on("LZ4F_MI355X_NO_GROUPS"); no_window = on("LZ4F_MI355X_NO_WINDOW"); serial_walk = on("LZ4F_MI355X_SERIAL_WALK");
-    no_trailer = on("LZ4F_MI355X_NO_TRAILER"); no_density_probe = on("LZ4F_MI355X_NO_DENSITY_PROBE"); no_content_check = on("LZ4F_MI355X_NO_CONTENT_CHECK"); prof = on("LZ4F_MI355X_PROF"); e1_sync = on("LZ4F_MI355X_E1_SYNC");
+    no_trailer = on("LZ4F_MI355X_NO_TRAILER"); no_density_probe = on("LZ4F_MI355X_NO_DENSITY_PROBE"); no_spx = on("LZ4F_MI355X_NO_SPX"); no_content_check = on("LZ4F_MI355X_NO_CONTENT_CHECK"); prof = on("LZ4F_MI355X_PROF"); e1_sync = on("LZ4F_MI355X_E1_SYNC");
     chain_gate = 0; if (const char* v = getenv("LZ4F_MI355X_CHAIN_GATE")) { const int g = atoi(v); if (g > 0 && g < (1 << 20)) chain_gate = g; }
     decode_mode = 0; if (const char* v = getenv("LZ4F_MI355X_DECODE")) decode_mode = v[0];
     e1_run = 0; if (const char* v = getenv("LZ4F_MI355X_E1_RUN")) { const int g = atoi(v); if (g >= 1 && g <= 4096) e1_run = (unsigned)g; }
@@ -163,7 +163,7 @@ lz4f_mi355x_engine::~lz4f_mi355x_engine()
 {
     (void)hipSetDevice(device);
     (void)hipStreamSynchronize((hipStream_t)stream);
-    desc.release(); seqcnt.release(); selfix.release(); selfcnt.release(); postab.release(); pdbuf.release();
+    desc.release(); seqcnt.release(); spx.release(); selfix.release(); selfcnt.release(); postab.release(); pdbuf.release();
     info.release(); recs.release(); e1_scratch.release(); walkbuf.release(); density.release(); ixtmp.release(); table.release(); blk_bytes.release(); res.release(); bad.release();
     d_in.release(); d_out.release();
     h_in.release(); h_out.release(); h_small.release();
@@ -444,6 +444,43 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 self_seqs = tot[9]; self_entries = tot[8];
             }
         }
+        bool spx_mode = false;
+        if (mode == 'f' && !j.linked && !d_index && j.block_size >= (256u << 10) && j.block_size <= (4u << 20) && !sw.no_index && !sw.no_selfindex && !sw.no_spx) {
+            // A frame of big independent blocks without an index (a foreign one: `lz4 -c`, LZ4F_compressFrame): the blocks are cut into
+            // stretches by lanes that start at guessed tokens and are stitched where they meet (decode_spx.cuh); the stretches are
+            // parsed in parallel, then the indexed kernels.  One host synchronisation (the totals size the descriptor workspace);
+            // dense payloads (k_density_probe) and anything odd stay with the generic decoders.
+            const uint32_t cpb = j.block_size / pick_chunk_size(j.block_size);
+            const size_t fixed = ix_entries_at(n_max, cpb);
+            if (selfcnt.ensure((size_t)n_max * 8 + 64) || seqcnt.ensure(256 + (size_t)n_max * (8 + 8 * IXL_PUB)) || selfix.ensure(fixed + 64) || density.ensure(64) ||
+                spx.ensure((size_t)n_max * ((SPX_MAXSEG + 1) * sizeof(SpxPoint) + 4) + 64))
+                return make_err(LZ4F_ERROR_allocation_failed);
+            uint32_t* cnt = (uint32_t*)selfcnt.p; uint32_t* osz = cnt + n_max;
+            SpxPoint* spt = (SpxPoint*)spx.p; uint32_t* snr = (uint32_t*)((uint8_t*)spx.p + (size_t)n_max * (SPX_MAXSEG + 1) * sizeof(SpxPoint));
+            HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 64, st));
+            hipLaunchKernelGGL(k_density_probe, dim3(1), dim3(64), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, (uint32_t*)density.p);
+            hipLaunchKernelGGL(k_spx_index, dim3(n_max), dim3(128), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, cnt, osz,
+                               spt, snr, (uint32_t*)seqcnt.p, sw.no_density_probe ? (const uint32_t*)nullptr : (const uint32_t*)density.p + 1);
+            uint32_t tot[10];
+            for (int pass = 0; pass < 2; pass++) {
+                hipLaunchKernelGGL(k_selfindex_scan, dim3(1), dim3(1024), 0, st, tbl, (const ResultRec*)d_res, n_max, (const uint32_t*)cnt, (const uint32_t*)osz,
+                                   selfix.p, cpb, (uint64_t)j.dst_cap, j.block_size, (uint32_t*)seqcnt.p, 1u);
+                if (pass == 1) break;
+                HIP_TRY(hipMemcpyAsync(tot, seqcnt.p, sizeof(tot), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                if (sw.prof) fprintf(stderr, "spx: flags %u, %u sequences in %u blocks, %u stretches walked by the stitching thread\n", tot[0], tot[9], n_max, tot[2]);
+                if (tot[0] != 0 || tot[9] == 0) break;
+                const void* before = selfix.p;
+                if (selfix.ensure(fixed + (size_t)tot[8] * sizeof(IxEntry) + 64)) return make_err(LZ4F_ERROR_allocation_failed);
+                if (selfix.p == before) break;                                   // (same buffer: the block table is already in it)
+            }
+            if (tot[0] == 0 && tot[9] != 0) {
+                d_index = selfix.p; index_size = fixed + (size_t)tot[8] * sizeof(IxEntry);
+                self_indexed = true; spx_mode = true;
+                plan |= LZ4F_MI355X_PATH_SELF_INDEX;
+                self_seqs = tot[9]; self_entries = tot[8];
+            }
+        }
         // (linked frames: only with a table that has every block's output position - the compressor's, or the one just made)
         if (mode == 'f' && d_index && index_size >= sizeof(IxHeader) && (!j.linked || self_indexed || ((j.d_table || j.table_in_place) && j.hist0 <= 65536)) &&
             !sw.no_index) {
@@ -482,6 +519,11 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 hipLaunchKernelGGL(k_check_index, dim3(1), dim3(64), 0, st, (const void*)d_index, (uint64_t)index_size, n_ix, cpb, chunk,
                                    (uint64_t)ix_seq_cap, (uint32_t*)seqcnt.p, (const ResultRec*)d_res);
                 uint32_t n_lanes = ix_entries_hint > n_ix ? ix_entries_hint : n_ix;           // (grid-stride inside: a hint is enough)
+                if (spx_mode)                                                                 // (no entries: the stretches between the blocks' check lines)
+                    hipLaunchKernelGGL(k_spx_parse, dim3(n_ix), dim3(128), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl, (const ResultRec*)d_res, n_ix,
+                                       (const void*)d_index, (const SpxPoint*)spx.p, (const uint32_t*)((const uint8_t*)spx.p + (size_t)n_max * (SPX_MAXSEG + 1) * sizeof(SpxPoint)),
+                                       (SeqDesc*)desc.p, (uint32_t*)seqcnt.p);
+                else
                 hipLaunchKernelGGL(k_parse_indexed, dim3((n_lanes + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap,
                                    (const BlockOut*)tbl, (const void*)d_index, n_ix, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, lk, (uint64_t)j.hist0);
                 const uint64_t trace_span = (uint64_t)n_ix * j.block_size;            // (the last block may be short)

@@ -58,6 +58,7 @@ struct lz4f_mi355x_engine {
     lz4f::DevBuf walkbuf;                                  // frames without a block table: the parallel walk's candidates
     lz4f::DevBuf density;                                  // k_density_probe: which decoder a frame of big blocks without an index goes to
     lz4f::DevBuf e1_scratch;                               // pass E1: per workgroup, the slice lists of the tile it is searching
+    lz4f::DevBuf spx;                                      // big independent blocks without an index: the true points of every block's check lines (decode_spx.cuh)
     lz4f::DevBuf selfix, selfcnt;                          // linked frames without an index: the one made here, and its per-block counts
     lz4f::DevBuf pdbuf;                                    // dense frames by pointer doubling: a word per output byte
     lz4f::DevBuf postab;                                   // dense frames: output position / 64 -> sequence (k_build_postab)
@@ -67,7 +68,7 @@ struct lz4f_mi355x_engine {
     // A-B and development switches: read from the environment ONCE, when the engine is made (engines of the host-pointer calls
     // live in a pool: lz4f_mi355x_release_engines() makes the next ones read it again)
     struct Switches {
-        bool no_index, no_selfindex, no_resolve, no_trace, no_doubling, trace_always, no_groups, no_window, serial_walk, no_trailer, no_content_check, no_density_probe, prof, e1_sync;
+        bool no_index, no_selfindex, no_resolve, no_trace, no_doubling, trace_always, no_groups, no_window, serial_walk, no_trailer, no_content_check, no_density_probe, no_spx, prof, e1_sync;
         int chain_gate; char decode_mode; unsigned e1_run, e1_solo, seed; unsigned long long wait_ticks;
         void read();
     } sw;

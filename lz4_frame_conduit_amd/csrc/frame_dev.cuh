@@ -11,6 +11,7 @@
 #include "decode_linked.cuh"
 #include "encode.cuh"
 #include "decode_indexed.cuh"
+#include "decode_spx.cuh"
 
 namespace lz4f {
 
@@ -224,6 +225,9 @@ __global__ __launch_bounds__(64) void k_xxh32_content(const uint8_t* __restrict_
 }
 
 // ------------------------------- frame walk -----------------------------------------------------
+#ifndef WK_AHEAD          // lines per lane the serial walk touches around where the size word after the next one should be (1: 8 KiB, 2: 16 KiB, 4: 32 KiB)
+#define WK_AHEAD 1
+#endif
 __device__ __forceinline__ uint32_t rd32_any(const uint8_t* p)
 {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
@@ -239,7 +243,7 @@ __device__ uint32_t xxh32_small(const uint8_t* p, uint32_t len)   // len < 16: h
 
 // Single thread: the walk is a pointer chase (each size word's position depends on all earlier
 // ones).  Same validation order as the oracle's orc_decompress_frame.
-__global__ void k_walk_frame(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint64_t dst_cap,
+__global__ __launch_bounds__(64) void k_walk_frame(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint64_t dst_cap,
                              BlockOut* __restrict__ table, uint32_t table_cap, ResultRec* __restrict__ res, const uint32_t* __restrict__ walked = nullptr)
 {
     // One wave, every lane walking the same chain (all stores are of identical values to identical addresses): what the other 63
@@ -248,7 +252,7 @@ __global__ void k_walk_frame(const uint8_t* __restrict__ frame, uint64_t frame_c
     if (walked && *walked) return;                                      // the parallel walk (below) has written table and result
     const uint32_t lane = lane_id();
     ResultRec r; r.size = 0; r.consumed = 0; r.status = ST_OK; r.n_blocks = 0; r.first_bad_block = 0xFFFFFFFFu; r.flags = 0;
-    auto fail = [&](uint32_t st) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); r.status = st; *res = r; };      // (a read-ahead may be in flight)
+    auto fail = [&](uint32_t st) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory", "v250", "v251", "v252", "v253"); r.status = st; *res = r; };      // (a read-ahead may be in flight)
     if (frame_cap < 7) return fail(12);                              // frameHeader_incomplete
     const uint32_t magic = rd32_any(frame);
     if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {                      // skippable frame: no output
@@ -277,14 +281,16 @@ __global__ void k_walk_frame(const uint8_t* __restrict__ frame, uint64_t frame_c
     uint64_t pos = hsize, out = 0;
     uint32_t n = 0;
     // Every hop is a dependent read that misses every cache: 0.66 us per block (4 GiB in 4 MiB blocks: 0.68 ms).  Where the size word
-    // AFTER the next one will be is not known - but blocks of one stream are often of similar size, so the 64 lanes touch the 8 KiB
-    // around where it would be if the next block were as big as this one (a line each).  A right guess makes that hop an L2 hit, a
-    // wrong one costs nothing: the words read ahead are only looked at to keep the loads alive.
+    // AFTER the next one will be is not known - but blocks of one stream are often of similar size, so the 64 lanes touch the 32 KiB
+    // around where it would be if the next block were as big as this one (four lines each; round 2: one line each, 8 KiB, which
+    // caught about half of the hops of the bench's frame).  A right guess makes that hop an L2 hit, a wrong one costs nothing: the
+    // words read ahead are only looked at to keep the loads alive.
     // (The read-ahead must not be waited for: memory operations return in order, so the next size word is asked for FIRST and the
-    // read-ahead behind it, and the wait is for all but the youngest - which the compiler cannot be told, hence the asm.  `ahead`
-    // stays a live register until the next pair is issued, by when it has arrived.)
+    // read-ahead behind it, and the wait is for all but the four youngest - which the compiler cannot be told, hence the asm.  The
+    // read-ahead lands in v250..v253, named in the asm and in its clobber list: registers the compiler keeps out of for the whole
+    // kernel, so a load that is still in flight when the next statement runs cannot land in a register that has got another job.)
     if (frame_cap - pos < 4) return fail(12);
-    uint32_t w = *(const u32_ua*)(frame + pos), ahead = 0;
+    uint32_t w = *(const u32_ua*)(frame + pos);
     for (;;) {
         pos += 4;
         if (w == 0) break;
@@ -299,15 +305,34 @@ __global__ void k_walk_frame(const uint8_t* __restrict__ frame, uint64_t frame_c
         pos += (uint64_t)csz + 4 * bck;
         n++;
         if (frame_cap - pos < 4) return fail(12);
+#if WK_AHEAD == 4
+        const uint64_t guess = pos + 4 + csz + 4 * bck + (uint64_t)lane * 128u;          // (lane 0 of the third group = the guess itself)
+        const bool inside = guess >= 16384u + 4u && guess + 16384u + 4u <= frame_cap;
+        const uint8_t* pw = frame + pos;
+        const uint8_t* pa = inside ? frame + ((guess - 16384u) & ~(uint64_t)3) : pw;
+        const uint64_t st8 = inside ? 8192u : 0u;
+        const uint8_t* pb = pa + st8; const uint8_t* pc = pb + st8; const uint8_t* pd = pc + st8;
+        asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword v250, %2, off\n\tglobal_load_dword v251, %3, off\n\tglobal_load_dword v252, %4, off\n\t"
+                     "global_load_dword v253, %5, off\n\ts_waitcnt vmcnt(4)"
+                     : "=&v"(w) : "v"(pw), "v"(pa), "v"(pb), "v"(pc), "v"(pd) : "memory", "v250", "v251", "v252", "v253");
+#elif WK_AHEAD == 2
+        const uint64_t guess = pos + 4 + csz + 4 * bck + (uint64_t)lane * 128u;          // (lane 0 of the second group = the guess itself)
+        const bool inside = guess >= 8192u + 4u && guess + 8192u + 4u <= frame_cap;
+        const uint8_t* pw = frame + pos;
+        const uint8_t* pa = inside ? frame + ((guess - 8192u) & ~(uint64_t)3) : pw;
+        const uint8_t* pb = pa + (inside ? 8192u : 0u);
+        asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword v250, %2, off\n\tglobal_load_dword v251, %3, off\n\ts_waitcnt vmcnt(2)"
+                     : "=&v"(w) : "v"(pw), "v"(pa), "v"(pb) : "memory", "v250", "v251", "v252", "v253");
+#else
         const uint64_t guess = pos + 4 + csz + 4 * bck + (uint64_t)lane * 128u;          // lane 32 = the guess itself
         const bool inside = guess >= 4096u + 4u && guess - 4096u + 4u <= frame_cap;
         const uint8_t* pw = frame + pos;
         const uint8_t* pa = inside ? frame + ((guess - 4096u) & ~(uint64_t)3) : pw;
-        asm volatile("" :: "v"(ahead));
-        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off\n\ts_waitcnt vmcnt(1)" : "=&v"(w), "=&v"(ahead) : "v"(pw), "v"(pa) : "memory");
+        asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword v250, %2, off\n\ts_waitcnt vmcnt(1)"
+                     : "=&v"(w) : "v"(pw), "v"(pa) : "memory", "v250", "v251", "v252", "v253");
+#endif
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" :: "v"(ahead));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory", "v250", "v251", "v252", "v253");
     if ((flg >> 2) & 1) { if (frame_cap - pos < 4) return fail(12); pos += 4; }   // content checksum: verified behind the decode (k_xxh32_content)
     r.n_blocks = n; r.consumed = pos; r.size = content;             // size = declared content size until decode fills it
     *res = r;

@@ -864,9 +864,78 @@ def test_inband_trailer_interop_and_robustness(L):
 
 
 @pytest.mark.gpu
+def test_foreign_big_independent_blocks_stretch_parallel(L):
+    """Frames of big independent blocks that come without an index - what LZ4F_compressFrame / `lz4 -B7` write and the reference's
+    decompress tests feed (test/Main.hs:33-36) - are cut into stretches by the decoder itself (decode_spx.cuh: lanes that start at
+    guessed tokens, stitched where the true chain lands exactly on a lane's start) and go through the indexed kernels.  liblz4's
+    bytes in, the input out, for long sequences, runs, stored blocks inside, short last blocks, block checksums, 256 KiB .. 4 MiB
+    blocks; the same frames through the generic decoders (LZ4F_MI355X_NO_SPX); device-resident calls report the path; and
+    single-byte mutations get the oracle's verdicts (whoever decodes them in the end)."""
+    import torch
+    from lz4_frame_conduit_amd.device import Engine, DeviceCodecError
+    rng = np.random.default_rng(11)
+    s50 = datagen.synth50(13 << 20, 77)
+    noise = rng.integers(0, 256, 5 << 20, dtype=np.uint8)
+    inputs = {
+        "synth50+tail": np.concatenate([s50, noise[:70001]]),
+        "stored inside": np.concatenate([s50[:5 << 20], noise[:(4 << 20) + 333], s50[5 << 20:9 << 20]]),
+        "runs": np.concatenate([np.zeros(3 << 20, dtype=np.uint8), s50[:2 << 20], np.full(2500000, 7, dtype=np.uint8)]),
+        "structured": np.frombuffer(datagen.structured(6 << 20, 5), dtype=np.uint8),
+        "ints": np.frombuffer(datagen.ints_100000() * 9, dtype=np.uint8),
+        "one short block": s50[:300000],
+        "tiny": s50[:13],
+    }
+    frames = []
+    for name, data in inputs.items():
+        for kw in (dict(bsid=7, indep=1), dict(bsid=6, indep=1, bck=1), dict(bsid=5, indep=1, cck=1)):
+            frames.append((name, kw, data, oracle.conduit_compress(data.tobytes(), oracle.mkprefs(**kw))))
+    import os
+    for env in ({}, {"LZ4F_MI355X_NO_SPX": "1"}):
+        os.environ.update(env)
+        L.lz4f_mi355x_release_engines()
+        try:
+            eng = Engine(0)
+            for name, kw, data, fr in frames:
+                out, used = gpu_decompress_frame(L, fr, len(data) + 8)                       # host-pointer call (slabs)
+                assert used == len(fr) and out == data.tobytes(), (name, kw, env)
+                dev = torch.from_numpy(np.frombuffer(fr + bytes(32), dtype=np.uint8).copy()).cuda()
+                back = torch.zeros(len(data) + 16, dtype=torch.uint8, device="cuda")
+                eng.decompress_frame_async(dev, len(fr), back)                               # device-resident call
+                r = eng.result()
+                assert r.size == len(data) and r.consumed == len(fr) and back[:len(data)].cpu().numpy().tobytes() == data.tobytes(), (name, kw, env)
+                path = int(r.flags) >> 12
+                if name in ("synth50+tail", "stored inside") and kw["bsid"] >= 6:
+                    want = 0 if env else PATH["self_index"] | PATH["indexed"]
+                    assert path & (PATH["self_index"] | PATH["indexed"] | PATH["dropped"]) == want, (name, kw, env, hex(path))
+            eng.close()
+        finally:
+            for k in env: os.environ.pop(k, None)
+            L.lz4f_mi355x_release_engines()
+    # mutations: the verdict (and, when accepted, the bytes) of the oracle
+    name, kw, data, base = frames[0]
+    cap = len(data) + 8
+    diff = []
+    for i in range(60):
+        pos = int(rng.integers(7, len(base))); x = int(rng.integers(1, 256))
+        if i < 12: pos = 7 + int(rng.integers(0, 3000)) + (i % 3) * 2150000                 # some near the starts of the first blocks
+        bad = bytearray(base); bad[pos] ^= x; bad = bytes(bad)
+        try:
+            want, _ = oracle.decompress_frame(bad, cap); ov = "ok"
+        except oracle.OracleError as e:
+            want, ov = None, str(e)
+        try:
+            got, _ = gpu_decompress_frame(L, bad, cap); gv = "ok"
+        except RuntimeError as e:
+            got, gv = None, str(e).split(" | ")[0]
+        if (ov == "ok") != (gv == "ok") or (ov == "ok" and got != want): diff.append((pos, x, ov, gv))
+    assert not diff, diff[:5]
+
+
+@pytest.mark.gpu
 def test_decode_path_by_input_class(L):
     """Which kernels a decompress call launches is a function of the call alone - the arguments, the frame's header and trailer,
-    the switches the engine was made with - and is reported in result.flags (LZ4F_MI355X_PATH_*).  One case per input class,
+    the payload's density where the frame has to be indexed here, the switches the engine was made with - and is reported in
+    result.flags (LZ4F_MI355X_PATH_*).  One case per input class,
     run in two different orders on one engine and on a fresh engine: the same path every time, and the source's bytes."""
     import torch
     from lz4_frame_conduit_amd.device import Engine
@@ -874,9 +943,11 @@ def test_decode_path_by_input_class(L):
     s50, text = datagen.synth50(16 << 20, 21), datagen.synth_text(8 << 20, 22)
     def foreign(data, **kw): return oracle.conduit_compress(data.tobytes(), oracle.mkprefs(**kw))
     cases = {}      # name -> (kind, data, prefs kw, must have, must not have)
-    # (big independent blocks without an index: fused workgroups AND the wave-per-block decoder are launched, a probe of the payload's
-    # density on the device lets one of them run - text goes to the lanes, long sequences to the fused parser)
-    cases["foreign 4M independent"] = ("foreign", s50, dict(bsid=7, indep=1), P["fused"] | P["wave_per_block"], P["table"] | P["trailer"] | P["parallel_walk"] | P["indexed"] | P["window"])
+    # (big independent blocks without an index: long sequences -> the decoder cuts the blocks into stretches itself (decode_spx.cuh) and
+    # runs the indexed kernels; dense payloads (a probe on the device decides) -> fused workgroups AND the wave-per-block decoder are
+    # launched and one of them runs - text goes to the lanes)
+    cases["foreign 4M independent"] = ("foreign", s50, dict(bsid=7, indep=1), P["self_index"] | P["indexed"] | P["fused"], P["table"] | P["trailer"] | P["parallel_walk"] | P["window"] | P["dropped"] | P["wave_per_block"])
+    cases["foreign 1M independent"] = ("foreign", s50, dict(bsid=6, indep=1), P["self_index"] | P["indexed"] | P["fused"], P["table"] | P["trailer"] | P["parallel_walk"] | P["window"] | P["dropped"] | P["wave_per_block"])
     cases["foreign 4M independent text"] = ("foreign", text, dict(bsid=7, indep=1), P["fused"] | P["wave_per_block"], P["table"] | P["trailer"] | P["parallel_walk"] | P["indexed"] | P["window"])
     cases["foreign 64K independent"] = ("foreign", s50, dict(bsid=4, indep=1), P["parallel_walk"] | P["wave_per_block"], P["table"] | P["trailer"] | P["indexed"] | P["fused"])
     cases["foreign 64K independent, short"] = ("foreign", s50[:300000], dict(bsid=4, indep=1), P["wave_per_block"], P["parallel_walk"] | P["trailer"] | P["indexed"] | P["fused"])
@@ -887,7 +958,7 @@ def test_decode_path_by_input_class(L):
     # (text has more sequences than an index of the recommended size holds: the compressor marks it unusable, the trailer carries the block list alone)
     cases["in-band 4M text"] = ("inband", text, dict(bsid=7, indep=1), P["trailer"] | P["fused"] | P["wave_per_block"], P["table"] | P["indexed"] | P["hops"] | P["self_index"] | P["parallel_walk"])
     cases["table + index 4M"] = ("indexed", s50, dict(bsid=7, indep=1), P["table"] | P["indexed"] | P["fused"], P["trailer"] | P["parallel_walk"] | P["self_index"] | P["dropped"])
-    cases["table 4M"] = ("table", s50, dict(bsid=7, indep=1), P["table"] | P["fused"] | P["wave_per_block"], P["trailer"] | P["parallel_walk"] | P["indexed"])
+    cases["table 4M"] = ("table", s50, dict(bsid=7, indep=1), P["table"] | P["self_index"] | P["indexed"] | P["fused"], P["trailer"] | P["parallel_walk"] | P["dropped"])
     made = {}
     def prepare(eng, name):
         kind, data, kw, _, _ = cases[name]
