@@ -197,6 +197,17 @@ LZ4F_MI355X_API size_t lz4f_mi355x_engine_create(lz4f_mi355x_engine** out, int d
 LZ4F_MI355X_API size_t lz4f_mi355x_engine_free(lz4f_mi355x_engine* e);
 LZ4F_MI355X_API void*  lz4f_mi355x_engine_stream(lz4f_mi355x_engine* e);
 
+/* DETERMINISM.  liblz4 maps equal input to equal bytes.  This encoder, by default, does not: the sixteen waves of a workgroup search
+ * neighbouring slices of a 64 KiB tile at once and share one hash table, so which earlier occurrence a position finds depends on
+ * which wave got there first.  Every frame is a valid LZ4 frame that decodes to the input, and the size varies by ~1e-5 between
+ * runs (4 GiB of the bench input: 2 189 936 735 .. 2 189 966 976 bytes) - but two compressions of the same input are in general
+ * NOT byte-identical.  Where that matters (reproducible archives, deduplication, content-addressed stores) switch the engine to
+ * the deterministic parse: one wave per workgroup takes the slices in order (the others only move data), equal input then gives
+ * equal bytes, at about a tenth of the match finder's speed (measured: DESIGN.md section 4).  Engines of the host-pointer calls
+ * and of the LZ4F_* streaming functions read LZ4F_MI355X_DETERMINISTIC=1 from the environment when they are made.
+ * Decoding is deterministic always. */
+LZ4F_MI355X_API size_t lz4f_mi355x_engine_set_deterministic(lz4f_mi355x_engine* e, int enable);
+
 /* Optional per-kernel timing with HIP events recorded on the engine's stream around each kernel of the last
  * compress / decompress call.  get_timing synchronises the stream and fills ms[] (milliseconds):
  *   [0] find_matches  [1] layout  [2] emit  [3] xxh32 (compress)  [4] walk  [5] xxh32 (verify)  [6] decode (all kernels)

@@ -278,7 +278,9 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
     e1_fill(sh, src, org, hist0, E1_TILE + len0, tid);                   // history + first tile
     __syncthreads();
     // the history's positions into the table, every seed_stride-th, in position order (later ones win)
-    for (uint32_t p = hist0 + tid * g.seed_stride; p < E1_TILE; p += NT * g.seed_stride)
+    // (deterministic parse: by one wave, so that which of two positions with one slot stays is a matter of order, not of timing)
+    const uint32_t nt_seed = (g.e1_solo & 1u) ? WAVE : NT;
+    if (tid < nt_seed) for (uint32_t p = hist0 + tid * g.seed_stride; p < E1_TILE; p += nt_seed * g.seed_stride)
         if (p + 4 <= E1_TILE + len0) { const uint32_t hv = e1_mix(e1_ld32(sh.ring, p)); sh.table[e1_slot(hv)] = (uint16_t)p; sh.tags[e1_slot(hv)] = (uint8_t)e1_tag(hv); }
 
     // ---- a tile's slice lists -> its record list.  One wave does it (the last one), on its own, while the others are already
@@ -378,6 +380,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
 
     if (tid == 0) { sh.mode = 0; sh.cov = E1_TILE; sh.hits = 0; sh.first = 0; sh.next = 1; sh.pieces[0] = 0; sh.pieces[1] = 0; }
     if (tid < 16) sh.cur[tid] = 0;
+    uint32_t mode_tile = 0;                                              // (deterministic parse) sh.mode as it stood when this tile began
     bool pend = false;                                                   // a tile whose lists are not merged yet
     uint32_t p_c = 0, p_par = 0, p_ts = 0, p_te = 0, p_bend = 0, p_ns = 0;
     __syncthreads();                                                     // the first tile is in the ring, the table is seeded, counters are set
@@ -434,7 +437,9 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
             // where they are short - the waves then work within 2 KiB of each other, and what a position's nearest earlier
             // occurrence usually is (text) has been indexed when it is probed.  A tile's first 2 KiB decide for a run's first tile,
             // the later tiles go by the ones before.
-            uint32_t mode = uni(__hip_atomic_load(&sh.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            // (deterministic parse: the mode word is written by the merge wave whenever it gets there, so it is looked at once per tile,
+            // between the tile's two closing barriers, where the merge of the tile before has long finished)
+            uint32_t mode = (g.e1_solo & 1u) ? mode_tile : uni(__hip_atomic_load(&sh.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             // The tile's first slice goes to the first wave alone, and the others start when it is through (a poll with a budget:
             // going ahead without it costs ratio, nothing else).  Where the tile begins inside a long or periodic match - one hot
             // table slot per distinct four bytes, always holding a position of whoever is furthest ahead - that slice finds it,
@@ -464,6 +469,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
             if (mode == 0 && si >= 2 * E1_PROBE_SLICES) {
                 mode = uni(__hip_atomic_load(&sh.hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) > E1_DENSE_HITS ? 2u : 1u;
                 *(lane == 0 ? &sh.mode : &sh.idle[lane]) = mode;
+                mode_tile = mode;
             }
             const uint32_t cs = ts + si * E1_SLICE;
             const uint32_t ce = (cs + grab * E1_SLICE < te) ? cs + grab * E1_SLICE : te;
@@ -640,6 +646,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
         E1DBG(const unsigned long long q2 = clock64();)
         __builtin_amdgcn_s_waitcnt(0);                                   // my slice lists are written
         __syncthreads();                                                 // every slice is done: nobody reads the ring's older half any more
+        mode_tile = uni(__hip_atomic_load(&sh.mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         E1DBG(const unsigned long long q3 = clock64();)
         pend = true; p_c = c; p_par = par; p_ts = ts; p_te = te; p_bend = bend; p_ns = nslice;
 

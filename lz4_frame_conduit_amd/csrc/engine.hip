@@ -90,6 +90,7 @@ void lz4f_mi355x_engine::Switches::read()
     decode_mode = 0; if (const char* v = getenv("LZ4F_MI355X_DECODE")) decode_mode = v[0];
     e1_run = 0; if (const char* v = getenv("LZ4F_MI355X_E1_RUN")) { const int g = atoi(v); if (g >= 1 && g <= 4096) e1_run = (unsigned)g; }
     e1_solo = 0; if (const char* v = getenv("LZ4F_MI355X_E1_SOLO")) e1_solo = (unsigned)atoi(v);
+    if (on("LZ4F_MI355X_DETERMINISTIC")) e1_solo |= 1u;              // equal input -> equal bytes: one wave per workgroup parses, in order (see lz4f_mi355x_engine_set_deterministic)
     wait_ticks = 0; if (const char* v = getenv("LZ4F_MI355X_WAIT_TICKS")) { unsigned long long a = 0; if (sscanf(v, "%llu", &a) == 1) wait_ticks = a; }
     seed = 2; if (const char* v = getenv("LZ4F_MI355X_SEED")) { unsigned a = 0; if (sscanf(v, "%u", &a) == 1 && a >= 1 && a <= 64) seed = a; }
 }
@@ -366,6 +367,26 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             walked = &ws->done;
             plan |= LZ4F_MI355X_PATH_PARALLEL_WALK;
             if (sw.prof) { WalkState h; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(&h, ws, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "parallel walk: done %u overflow %u candidates %u first_end %u first_break %u (header ok %u, hsize %u, block %u)\n", h.done, h.overflow, h.total, h.first_end, h.first_break, h.head_ok, h.hsize, h.bs); }
+        }
+        else if (j.block_size > (256u << 10) && j.frame_cap >= (size_t)192 * j.block_size && !sw.serial_walk) {      // (~0.15 ms whatever the frame: pays from ~330 blocks of half their size on)
+            // big blocks: seeds found in parallel, a lane per seed walking to the next one (frame_dev.cuh); the list is checked link by
+            // link like the small blocks' candidates, and k_walk_frame behind walks the frame itself if it is not the chain
+            const size_t list_cap = (size_t)n_max + 1024;
+            const size_t at_seeds = 256, at_list = at_seeds + (WK_SEEDS + 1) * 8;
+            if (walkbuf.ensure(at_list + list_cap * 8)) return make_err(LZ4F_ERROR_allocation_failed);
+            WalkState* ws = (WalkState*)walkbuf.p;
+            unsigned long long* seeds = (unsigned long long*)((uint8_t*)walkbuf.p + at_seeds);
+            HIP_TRY(hipMemsetAsync(seeds, 0xFF, (WK_SEEDS + 1) * 8, st));
+            uint64_t* list = (uint64_t*)((uint8_t*)walkbuf.p + at_list);
+            const uint32_t lgrid = std::min<uint32_t>((uint32_t)((list_cap + 255) / 256), 4096u);
+            hipLaunchKernelGGL(k_walk_head, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, ws);
+            hipLaunchKernelGGL(k_walk_seeds, dim3(WK_SEEDS * wk_seed_pieces(j.block_size)), dim3(256), 0, st, j.d_frame, j.frame_cap, (const WalkState*)ws, seeds);
+            hipLaunchKernelGGL(k_walk_chains, dim3(1), dim3(WK_SEEDS), 0, st, j.d_frame, j.frame_cap, ws, (const unsigned long long*)seeds, list, (uint32_t)std::min<size_t>(list_cap, 0xFFFFFFFFu));
+            hipLaunchKernelGGL(k_walk_link, dim3(lgrid), dim3(256), 0, st, j.d_frame, j.frame_cap, j.dst_cap, ws, (const uint64_t*)list, tbl, n_max);
+            hipLaunchKernelGGL(k_walk_verdict, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, j.dst_cap, ws, (const uint64_t*)list, n_max, (ResultRec*)d_res);
+            walked = &ws->done;
+            plan |= LZ4F_MI355X_PATH_PARALLEL_WALK;
+            if (sw.prof) { WalkState h; if (hipStreamSynchronize(st) == hipSuccess && hipMemcpy(&h, ws, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "seeded walk: done %u overflow %u entries %u first_end %u first_break %u\n", h.done, h.overflow, h.total, h.first_end, h.first_break); }
         }
         hipLaunchKernelGGL(k_walk_frame, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, j.dst_cap, tbl, n_max, (ResultRec*)d_res, walked);
         tick(4, true);
@@ -955,6 +976,12 @@ void* lz4f_mi355x_host_alloc(size_t size)
 void lz4f_mi355x_host_free(void* p) { if (p) (void)hipHostFree(p); }
 void* lz4f_mi355x_engine_stream(lz4f_mi355x_engine* e) { return e ? e->stream : nullptr; }
 
+size_t lz4f_mi355x_engine_set_deterministic(lz4f_mi355x_engine* e, int enable)
+{
+    if (!e) return make_err(LZ4F_ERROR_GENERIC);
+    if (enable) e->sw.e1_solo |= 1u; else e->sw.e1_solo &= ~1u;
+    return 0;
+}
 size_t lz4f_mi355x_engine_set_timing(lz4f_mi355x_engine* e, int enable)
 {
     if (!e) return make_err(LZ4F_ERROR_GENERIC);

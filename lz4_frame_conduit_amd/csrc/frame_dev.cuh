@@ -511,6 +511,118 @@ __global__ __launch_bounds__(1024) void k_walk_order(WalkChunk* __restrict__ chu
     if (t == 0) ws->total = s_carry;
 }
 
+// ---- big blocks: the walk from many seeds at once ----
+// A frame of 4 MiB blocks is a chain of ~1000 dependent reads that miss every cache (0.45 ms for the bench's frame), and looking at
+// every byte position (k_walk_cand) would read the whole frame.  But a window of maxBlockSize + 8 bytes anywhere in the frame holds
+// a size word, and a position that passes the plausibility test WK_SEED_HOPS times in a row is one (2^-9 per hop for random bytes).
+//   k_walk_seeds    workgroup s scans the frame from s / n of its length on, 512 KiB at a time, until it has the first such position
+//   k_walk_chains   a lane per seed follows the size words from its seed to the next lane's seed: all lanes hop at once, so the
+//                   chain of 1000 reads becomes chains of 1000 / n; the positions visited, in order, are the candidate list
+// and k_walk_link / k_walk_verdict decide as for small blocks: the list is THE walk iff every entry is exactly where the one in
+// front points, from the first byte behind the header to the EndMark.  A seed that is no block start breaks the chain where the
+// true one arrives next to it, and the frame is left to k_walk_frame behind: a wrong guess costs time, never changes the table.
+constexpr uint32_t WK_SEEDS = 64, WK_SEED_HOPS = 4, WK_SEED_PIECE = 131072, WK_SEED_LIST = 2048, WK_LANE_CAP = 192;
+constexpr uint64_t WK_NOSEED = ~0ull;
+__host__ __device__ inline uint32_t wk_seed_pieces(uint32_t bs) { return (bs + 64u + WK_SEED_PIECE - 1) / WK_SEED_PIECE; }
+// grid: WK_SEEDS x wk_seed_pieces(bs) workgroups - every 128 KiB piece of every window by a workgroup of its own; seeds[s] (preset to
+// WK_NOSEED) gets the lowest find.  Two phases per workgroup: the piece is streamed and the plausible positions (one in 512 of random
+// bytes) are put on a list in LDS; then a thread per listed position follows its chain.  (Following a chain where it is found puts
+// two to four dependent reads into every round of the stream: 0.27-0.43 ms for what is 0.05 ms of reading.)
+__global__ __launch_bounds__(256) void k_walk_seeds(const uint8_t* __restrict__ frame, uint64_t frame_cap, const WalkState* __restrict__ ws, unsigned long long* __restrict__ seeds)
+{
+    __shared__ uint32_t s_best, s_n;
+    __shared__ uint32_t s_list[WK_SEED_LIST];
+    if (!ws->head_ok) return;
+    const uint32_t bs = ws->bs, bck = ws->bck, hsize = ws->hsize, t = threadIdx.x;
+    const uint32_t npc = wk_seed_pieces(bs), s = blockIdx.x / npc, pc = blockIdx.x % npc;
+    if (s == 0) { if (t == 0 && pc == 0) seeds[0] = hsize; return; }     // (the first block's size word follows the header)
+    const uint64_t span = frame_cap - hsize;
+    const uint64_t a = hsize + (span / WK_SEEDS) * s;
+    uint64_t wend = a + bs + 64u; if (wend > frame_cap) wend = frame_cap;
+    const uint64_t pp = a + (uint64_t)pc * WK_SEED_PIECE;
+    if (pp >= wend) return;
+    const uint32_t hi_mask = ~((bs << 1) - 1u) & 0x7FFFFFFFu;
+    if (t == 0) { s_best = 0xFFFFFFFFu; s_n = 0; }
+    __syncthreads();
+    for (uint64_t p0 = pp; p0 < pp + WK_SEED_PIECE && p0 < wend; p0 += 16384u) {
+        // a thread looks at 64 positions of the round: four loads of 20 bytes asked for together
+        uint32_t w[4][5];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint64_t q = p0 + (uint64_t)k * 4096u + t * 16u;
+            w[k][0] = w[k][1] = w[k][2] = w[k][3] = w[k][4] = 0;
+            if (q + 20 <= wend) { const b16_ua x = *(const b16_ua*)(frame + q); w[k][0] = x.a; w[k][1] = x.b; w[k][2] = x.c; w[k][3] = x.d; w[k][4] = *(const u32_ua*)(frame + q + 16); }
+            else for (uint32_t b = 0; b < 20 && q + b < wend; b++) w[k][b >> 2] |= (uint32_t)frame[q + b] << (8 * (b & 3));
+        }
+#pragma unroll 1
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint64_t q = p0 + (uint64_t)k * 4096u + t * 16u;
+            // (a size word's top byte is 0x00 or 0x80: where none of the 16 positions' top bytes is, there is nothing to look at - see k_walk_cand)
+            auto zb = [](uint32_t x) { const uint32_t y = x & 0x7F7F7F7Fu; return (y - 0x01010101u) & 0x80808080u; };
+            if (((zb(w[k][0]) & 0x80000000u) | zb(w[k][1]) | zb(w[k][2]) | zb(w[k][3]) | (zb(w[k][4]) & 0x00808080u)) == 0u) continue;
+            uint32_t plausible = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 16; i++) {
+                const uint32_t sh = (i & 3) * 8;
+                const uint32_t v = sh ? (w[k][i >> 2] >> sh) | (w[k][(i >> 2) + 1] << (32 - sh)) : w[k][i >> 2];
+                plausible |= ((v & hi_mask) == 0 && v != 0) ? 1u << i : 0u;
+            }
+#pragma unroll 1
+            while (plausible) {
+                const uint32_t i = (uint32_t)__builtin_ctz(plausible);
+                plausible &= plausible - 1;
+                if (q + i + 4 > wend) continue;
+                const uint32_t at = atomicAdd(&s_n, 1u);
+                if (at < WK_SEED_LIST) s_list[at] = (uint32_t)(q + i - pp);      // (a list that overflows - payload full of small words - loses finds: fewer seeds, never wrong ones)
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n = s_n < WK_SEED_LIST ? s_n : WK_SEED_LIST;
+    for (uint32_t j = t; j < n; j += 256) {
+        const uint32_t o = s_list[j];
+        uint64_t c = pp + o, nx = 0; bool end = false, good = true;
+#pragma unroll 1
+        for (uint32_t h = 0; h < WK_SEED_HOPS && good && !end; h++) { good = walk_step(frame, frame_cap, bs, bck, c, nx, end); if (h == 0 && end) good = false; c = nx; }
+        if (good) atomicMin(&s_best, o);
+    }
+    __syncthreads();
+    if (t == 0 && s_best != 0xFFFFFFFFu) atomicMin(&seeds[s], (unsigned long long)(pp + s_best));
+}
+// one workgroup, a thread per seed: follow the size words from my seed to the next thread's (the positions wait in LDS), then - after a
+// scan over the threads' counts - into the list
+__global__ __launch_bounds__(WK_SEEDS) void k_walk_chains(const uint8_t* __restrict__ frame, uint64_t frame_cap, WalkState* __restrict__ ws,
+                                                          const unsigned long long* __restrict__ seeds, uint64_t* __restrict__ list, uint32_t list_cap)
+{
+    __shared__ uint64_t s_seed[WK_SEEDS + 1];
+    __shared__ uint32_t s_cnt[WK_SEEDS];
+    __shared__ uint64_t s_pos[WK_LANE_CAP][WK_SEEDS];                    // [i][t]: thread t's i-th position (neighbouring threads in neighbouring banks)
+    if (!ws->head_ok) return;
+    const uint32_t bs = ws->bs, bck = ws->bck, t = threadIdx.x;
+    s_seed[t] = seeds[t];
+    if (t == 0) s_seed[WK_SEEDS] = WK_NOSEED;
+    __syncthreads();
+    uint64_t start = s_seed[t];
+    for (uint32_t k = 0; k < t; k++) if (s_seed[k] != WK_NOSEED && s_seed[k] >= start) start = WK_NOSEED;      // (a seed another thread in front has, or has passed: windows closer together than the blocks are long)
+    uint64_t stop = WK_NOSEED;
+    for (uint32_t k = t + 1; k < WK_SEEDS; k++) if (s_seed[k] != WK_NOSEED && s_seed[k] > start) { stop = s_seed[k]; break; }
+    uint64_t p = start; uint32_t c = 0; bool over = false;
+    while (p != WK_NOSEED && p < stop) {
+        uint64_t nx = 0; bool end = false;
+        if (!walk_step(frame, frame_cap, bs, bck, p, nx, end) || end) break;
+        if (c >= WK_LANE_CAP) { over = true; break; }
+        s_pos[c][t] = p;
+        c++; p = nx;
+    }
+    s_cnt[t] = over ? 0xFFFFFFFFu : c;
+    __syncthreads();
+    uint32_t base = 0, tot = 0; bool any_over = false;
+    for (uint32_t k = 0; k < WK_SEEDS; k++) { if (s_cnt[k] == 0xFFFFFFFFu) { any_over = true; break; } if (k == t) base = tot; tot += s_cnt[k]; }
+    if (any_over || tot > list_cap) { if (t == 0) ws->overflow = 1; return; }      // (uniform: every thread sees the same counts; k_walk_frame walks)
+    for (uint32_t i = 0; i < c; i++) list[base + i] = s_pos[i][t];
+    if (t == 0) ws->total = tot;
+}
+
 // A false candidate (a payload position whose bytes happen to chain) would break the list.  A true block start - but for the
 // first - is where another candidate's size word points, a false one practically never is: mark every candidate's
 // successor, then keep the first candidate and the marked ones.

@@ -48,6 +48,10 @@ class Engine:
 
     TIMING_SLOTS = ("find_matches", "layout", "emit", "xxh32_write", "walk", "xxh32_verify", "decode", "finish", "decode_parse", "decode_copy")
 
+    def set_deterministic(self, on: bool):
+        """Equal input -> equal bytes (one wave per workgroup parses, in order); about a tenth of the match finder's speed."""
+        _chk(self.L, self.L.lz4f_mi355x_engine_set_deterministic(self.h, 1 if on else 0))
+
     def set_timing(self, on: bool):
         _chk(self.L, self.L.lz4f_mi355x_engine_set_timing(self.h, 1 if on else 0))
 
