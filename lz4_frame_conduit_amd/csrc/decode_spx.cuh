@@ -13,11 +13,14 @@
 //                 guess) it walks on itself, from where the chain stands, until it meets a later lane's start.  Equality of
 //                 positions is the whole proof, so a wrong guess can cost time, never change the result.
 //                 Guessing well is what makes lanes meet.  Long literal runs (the payloads where a guessed chain would need ~20 KiB
-//                 to fall into step: it hops ~15 bytes at a time through 500 random bytes) announce themselves: a token with
-//                 literal length >= 270 is a byte 0xF? followed by 0xFF - one position in 4096 of random bytes.  A lane scans the
-//                 first 4 KiB of its segment for such a pair whose sequence leads to another one, and starts there (bench frame:
-//                 1-2 of 68 000 lanes guess wrong).  Without such a pair it starts at its segment's first byte; payloads of short
-//                 sequences are the dense ones, which do not come here (k_density_probe).
+//                 to fall into step: it hops 10-20 bytes at a time through 500 random bytes) announce themselves: a token with
+//                 literal length >= 270 is a byte 0xF? followed by 0xFF - one position in 4096 of random bytes.  The waves scan the
+//                 first KiB(s) of every segment for such pairs (64 lanes x 16 bytes of ONE segment per load), and a lane starts at
+//                 the first pair of its segment whose sequence leads to another one (bench frame: 1-4 of 68 000 lanes guess wrong).
+//                 Pairs but no token among them: the lane stays out and the lane in front walks on through its stretch.  No pair in
+//                 8 KiB: short sequences, where a chain started anywhere falls into step within a few hundred bytes - or a literal
+//                 run longer than that (the first 60 KiB of the bench's blocks, whose copies' sources lie in front of the block): a
+//                 lane that then crawls (an eighth of the bytes per hop the density probe saw) gives up after 64 hops.
 //                 Result per block: the sequence count, the output size, and a true (position, sequence number, output position)
 //                 at the start of every stretch.
 //   k_spx_parse   a lane per stretch: the sequences of that stretch -> descriptors, with parse_run()
@@ -31,7 +34,8 @@
 
 namespace lz4f {
 
-constexpr uint32_t SPX_SEG = 32768, SPX_SCAN = 4096, SPX_MAXSEG = (4u << 20) / SPX_SEG;      // lanes per block <= 128
+constexpr uint32_t SPX_SEG = 32768, SPX_SCAN = 8192, SPX_CAND = 6, SPX_MAXSEG = (4u << 20) / SPX_SEG;      // lanes per block <= 128
+constexpr uint32_t SPX_LANE_HOPS = 2048;                        // sequences a lane follows before it gives its stretch up (sparse payloads: >= 24 bytes per sequence, 1400 per stretch)
 constexpr uint32_t SPX_RESCUE = 1u << 16;                       // sequences the stitching thread may walk itself per block before it gives up
 constexpr uint32_t SPX_NONE = 0xFFFFFFFFu;
 struct SpxPoint { uint32_t pos, seq, out; };                    // a token position of the block's payload, the number of the sequence that starts there, its output position
@@ -78,40 +82,23 @@ __device__ __forceinline__ int spx_step(const uint8_t* __restrict__ in, uint32_t
 // lanes of a block: lane 0 starts at byte 0; lane u >= 1 exists while the stretch it looks for its start in lies inside the payload with room behind it
 __device__ __forceinline__ uint32_t spx_lanes(uint32_t csize)
 {
-    if (csize <= SPX_SEG + SPX_SCAN + 64u) return 1u;
-    const uint32_t n = (csize - SPX_SCAN - 64u - 1u) / SPX_SEG + 1u;     // largest u with u * SEG + SCAN + 64 < csize, + 1
+    if (csize <= SPX_SEG + SPX_SCAN + 2048u) return 1u;
+    const uint32_t n = (csize - SPX_SCAN - 2048u - 1u) / SPX_SEG + 1u;   // largest u with u * SEG + SCAN + 2 KiB < csize, + 1
     return n < SPX_MAXSEG ? n : SPX_MAXSEG;
 }
 
-// a likely token for a lane to start at: the first "0xF? 0xFF" pair in [from, from + SPX_SCAN) whose chain leads to another such pair
-// (or whose sequence is long enough to be no accident); `from` itself when there is none
-__device__ __forceinline__ uint32_t spx_guess(const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable, uint32_t from)
+// Is `at` a likely token?  Its sequence must lead to the payload's end or to another token that announces a long literal run.
+__device__ __forceinline__ bool spx_likely_token(const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable, uint32_t at)
 {
-    const uint32_t lim = (from + SPX_SCAN + 24u < csize) ? from + SPX_SCAN : (csize > 24u ? csize - 24u : 0u);
-    uint32_t tries = 0;
-    for (uint32_t a = from; a < lim; a += 8) {
-        const uint64_t x = pt_load8(in, a, readable), y = pt_load8(in, a + 8, readable);      // (independent loads: the compiler keeps several in flight)
-        // byte i is 0xF?, byte i + 1 is 0xFF, for i = 0..7 (bit tricks that stay inside their byte)
-        const uint64_t nx = (x >> 8) | (y << 56);
-        uint64_t m = x & (x >> 2); m = m & (m >> 1) & 0x1010101010101010ull;                                  // bit 4 of byte i: its bits 4..7 are all set
-        uint64_t ff = nx & (nx >> 4); ff = ff & (ff >> 2); ff = ff & (ff >> 1) & 0x0101010101010101ull;      // bit 0 of byte i: byte i + 1 is 0xFF
-        uint64_t cand = (m >> 4) & ff;
-        while (cand && tries < 8) {
-            const uint32_t i = (uint32_t)__builtin_ctzll(cand) >> 3;
-            cand &= cand - 1;
-            tries++;
-            SpxCur c{a + i, 0, 0, 0, 0};
-            spx_begin(in, readable, c);
-            const int r = spx_step(in, csize, readable, c);
-            if (r == 1) return a + i;
-            if (r == 0 && c.pos + 2 < csize) {
-                const uint32_t t = (uint32_t)c.w & 0xFFFFu;
-                if ((t & 0xF0u) == 0xF0u && (t >> 8) == 0xFFu) return a + i;               // the next token announces a long literal run as well
-            }
-        }
-        if (tries >= 8) break;
+    SpxCur c{at, 0, 0, 0, 0};
+    spx_begin(in, readable, c);
+    const int r = spx_step(in, csize, readable, c);
+    if (r == 1) return true;
+    if (r == 0 && c.pos + 2 < csize) {
+        const uint32_t t = (uint32_t)c.w & 0xFFFFu;
+        return (t & 0xF0u) == 0xF0u && (t >> 8) == 0xFFu;
     }
-    return from;
+    return false;
 }
 
 // ---- k_spx_index: a workgroup per block ----
@@ -122,6 +109,7 @@ __global__ __launch_bounds__(128) void k_spx_index(const uint8_t* __restrict__ f
                                                    const uint32_t* __restrict__ only_if)
 {
     __shared__ uint32_t s_g[SPX_MAXSEG + 1];                    // where lane u starts: its guess (lane 0: byte 0); [lanes]: SPX_NONE
+    __shared__ uint32_t s_cand[SPX_MAXSEG][SPX_CAND], s_ncand[SPX_MAXSEG];      // per lane: the first pairs of its segment
     __shared__ SpxPoint s_b[SPX_MAXSEG];                        // per lane: where its chain lands at or behind the NEXT lane's start (counts relative to its own start); pos SPX_NONE: nowhere
     __shared__ uint32_t s_end[SPX_MAXSEG];                      // per lane: 1 = s_b is the payload's end (pos == csize: the counts include the last sequence)
     if (res->status != ST_OK) return;
@@ -138,24 +126,108 @@ __global__ __launch_bounds__(128) void k_spx_index(const uint8_t* __restrict__ f
     const uint32_t nl = spx_lanes(csize);
     // ---- every lane's start: a guess (no overlap between lanes: lane u walks from its start to where lane u + 1 starts, and is
     // ---- followed by a true lane iff it lands exactly there) ----
-    if (u < nl) s_g[u] = u ? spx_guess(in, csize, readable, u * SPX_SEG) : 0u;
-    if (u == nl) s_g[u] = SPX_NONE;
-    __syncthreads();
-    if (u < nl) {
-        const uint32_t stop = s_g[u + 1];                                   // (SPX_NONE for the last lane: it walks to the end)
-        SpxPoint pb{SPX_NONE, 0, 0};
-        uint32_t ended = 0;
-        SpxCur c{s_g[u], 0, 0, 0, 0};
-        spx_begin(in, readable, c);
-        for (;;) {
-            if (c.pos >= stop) { pb = SpxPoint{c.pos, c.seq, c.out}; break; }
-            const int r = spx_step(in, csize, readable, c);
-            if (r == 1) { pb = SpxPoint{c.pos, c.seq, c.out}; ended = 1; break; }      // the payload's end (for a guessed chain: what looks like it)
-            if (r == 2) break;                                               // (a guessed chain may run into anything)
+#ifdef SPX_PROF
+    const unsigned long long z0 = clock64();
+#endif
+    // ---- where could a lane start?  The "0xF? 0xFF" pairs in the first KiB(s) of every lane's segment, found by the WAVE: 64 lanes x 16
+    // ---- bytes of one segment per load (a lane scanning its own segment 8 bytes at a time is 64 cache lines per wave instruction, and
+    // ---- the slowest lane of 2000 waves took 0.35 ms over it); a segment is read on, a KiB at a time, until it has shown a pair.
+    {
+        const uint32_t lane = u & 63u, wbase = u & ~63u;
+        for (uint32_t t = 0; t < 64; t++) {
+            const uint32_t uo = wbase + t;                                   // (wave-uniform)
+            if (uo == 0 || uo >= nl) continue;
+            const uint32_t from = uo * SPX_SEG;
+            uint32_t n = 0;
+            for (uint32_t a = from; a < from + SPX_SCAN && a + 1024u + 24u < csize && n == 0; a += 1024u) {
+                const uint8_t* q = in + a + lane * 16u;
+                typedef uint64_t u64u __attribute__((aligned(1)));
+                const uint64_t lo = *(const u64u*)q, hi = *(const u64u*)(q + 8);
+                const uint32_t nb = (uint32_t)q[16];                       // (the byte behind my sixteen: a pair may straddle two lanes)
+                // byte i is 0xF?, byte i + 1 is 0xFF (bit tricks that stay inside their byte)
+                const uint64_t nlo = (lo >> 8) | (hi << 56), nhi = (hi >> 8) | ((uint64_t)nb << 56);
+                uint64_t m0 = lo & (lo >> 2); m0 = m0 & (m0 >> 1) & 0x1010101010101010ull;
+                uint64_t m1 = hi & (hi >> 2); m1 = m1 & (m1 >> 1) & 0x1010101010101010ull;
+                uint64_t f0 = nlo & (nlo >> 4); f0 = f0 & (f0 >> 2); f0 = f0 & (f0 >> 1) & 0x0101010101010101ull;
+                uint64_t f1 = nhi & (nhi >> 4); f1 = f1 & (f1 >> 2); f1 = f1 & (f1 >> 1) & 0x0101010101010101ull;
+                const uint64_t c0 = (m0 >> 4) & f0, c1 = (m1 >> 4) & f1;      // bit 0 of byte i
+                // sixteen bits per lane, bit i = byte i of my sixteen starts a pair
+                uint32_t bits = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) { bits |= (uint32_t)((c0 >> (8 * i)) & 1ull) << i; bits |= (uint32_t)((c1 >> (8 * i)) & 1ull) << (8 + i); }
+                uint64_t have = __ballot(bits != 0);
+                while (have && n < SPX_CAND) {                               // the first few, in position order
+                    const uint32_t L = (uint32_t)__builtin_ctzll(have);
+                    uint32_t bl = (uint32_t)__builtin_amdgcn_readlane((int)bits, (int)L);
+                    while (bl && n < SPX_CAND) { const uint32_t i = (uint32_t)__builtin_ctz(bl); bl &= bl - 1; if (lane == 0) s_cand[uo][n] = a + L * 16u + i; n++; }
+                    have &= have - 1;
+                }
+            }
+            if (lane == 0) s_ncand[uo] = n;
         }
-        s_b[u] = pb; s_end[u] = ended;
     }
     __syncthreads();
+    // ---- every lane's start: the first of its segment's pairs that looks like a token (see spx_likely_token).  Pairs and none of them
+    // ---- a token: the lane stays out - a chain guessed into a long literal run hops ~10 bytes at a time (3000 hops through a stretch,
+    // ---- the whole kernel waiting for that one lane), and the lane in front walks on through this stretch instead.  No pair at all
+    // ---- in SPX_SCAN bytes: short sequences, where a chain started anywhere falls into step within a few hundred bytes.
+    if (u < nl) {
+        uint32_t g = 0;
+        if (u) {
+            const uint32_t n = s_ncand[u];
+            g = n ? SPX_NONE : u * SPX_SEG;
+            for (uint32_t k = 0; k < n; k++) { const uint32_t at = s_cand[u][k]; if (spx_likely_token(in, csize, readable, at)) { g = at; break; } }
+        }
+        s_g[u] = g;
+    }
+    if (u == nl) s_g[u] = SPX_NONE;
+#ifdef SPX_PROF
+    const unsigned long long z1 = clock64();
+#endif
+    __syncthreads();
+#ifdef SPX_PROF
+    const unsigned long long z2 = clock64();
+#endif
+    if (u < nl) {
+        SpxPoint pb{SPX_NONE, 0, 0};
+        uint32_t ended = 0;
+        if (s_g[u] != SPX_NONE) {
+            uint32_t stop = SPX_NONE;                                        // the next lane that has a start (none: this lane walks to the end)
+            for (uint32_t k = u + 1; k < nl; k++) if (s_g[k] != SPX_NONE && s_g[k] > s_g[u]) { stop = s_g[k]; break; }
+            SpxCur c{s_g[u], 0, 0, 0, 0};
+            spx_begin(in, readable, c);
+            // (a lane that started without a pair to go by - none in SPX_SCAN bytes - may stand in a literal run longer than that, where its
+            // chain crawls ~20 bytes per hop: if it makes less than an eighth of the way per hop that the probe saw sequences make in this
+            // frame, it gives up after 64 hops and the stitching thread walks the stretch)
+            const uint32_t slow = (u && s_g[u] == u * SPX_SEG && only_if) ? only_if[1] / 8u : 0u;
+            for (uint32_t hops = 0;; hops++) {
+                if (c.pos >= stop) { pb = SpxPoint{c.pos, c.seq, c.out}; break; }
+                if (slow && (hops & 63u) == 63u && c.pos - s_g[u] < hops * slow) break;
+#ifdef SPX_PROF
+                if (hops > SPX_LANE_HOPS) atomicAdd(&flags[48], 1u);
+#endif
+                if (hops > SPX_LANE_HOPS) break;                             // (a chain that crawls is a wrong guess: the stitching thread walks this stretch)
+                const int r = spx_step(in, csize, readable, c);
+                if (r == 1) { pb = SpxPoint{c.pos, c.seq, c.out}; ended = 1; break; }      // the payload's end (for a guessed chain: what looks like it)
+                if (r == 2) break;                                           // (a guessed chain may run into anything)
+            }
+        }
+        s_b[u] = pb; s_end[u] = ended;
+#ifdef SPX_PROF
+        if (s_g[u] == SPX_NONE) atomicAdd(&flags[49], 1u);
+        else if (u && s_g[u] == u * SPX_SEG) atomicAdd(&flags[50], 1u);
+        if (pb.pos == SPX_NONE && s_g[u] != SPX_NONE) atomicAdd(&flags[51], 1u);
+        atomicMax(&flags[52], pb.seq);
+#endif
+    }
+#ifdef SPX_PROF
+    const unsigned long long z3 = clock64();
+#endif
+    __syncthreads();
+#ifdef SPX_PROF
+    const unsigned long long z4 = clock64();
+    if ((u & 63) == 0) { atomicMax(&flags[40], (uint32_t)(z1 - z0)); atomicMax(&flags[41], (uint32_t)(z3 - z2)); atomicAdd(&flags[44], (uint32_t)((z1 - z0) >> 8)); atomicAdd(&flags[45], (uint32_t)((z3 - z2) >> 8)); }
+#endif
     if (u != 0) return;
     // ---- the stitch: lane 0 starts at byte 0 and is true; lane k + 1 is true iff the true chain lands exactly on its start.  A lane
     // ---- that is not (a wrong guess) is skipped: the thread walks on from where the true chain stands until it meets a later lane's start.
@@ -174,7 +246,7 @@ __global__ __launch_bounds__(128) void k_spx_index(const uint8_t* __restrict__ f
         while (!ended && !(kn < nl && s_g[kn] == nx.pos)) {
             // the true chain did not land on the next lane's start (or there is none): walk on from where it stands, to the start of
             // the first lane it meets (or the end); that lane's own walk is the true chain again
-            if (kn < nl && s_g[kn] < nx.pos) { kn++; continue; }             // (that lane's start lies behind us already)
+            if (kn < nl && (s_g[kn] == SPX_NONE || s_g[kn] < nx.pos)) { kn++; continue; }      // (a lane without a start, or one whose start lies behind us already)
             const uint32_t stop = kn < nl ? s_g[kn] : SPX_NONE;
             atomicAdd(&flags[2], 1u);                                        // (how often: a developer's number, LZ4F_MI355X_PROF prints it)
             SpxCur c{nx.pos, nx.seq, nx.out, 0, 0};
@@ -196,6 +268,9 @@ __global__ __launch_bounds__(128) void k_spx_index(const uint8_t* __restrict__ f
         }
         k = kn; cur = nx;
     }
+#ifdef SPX_PROF
+    { const unsigned long long z5 = clock64(); atomicMax(&flags[42], (uint32_t)(z5 - z4)); atomicMax(&flags[43], (uint32_t)(z5 - z0)); atomicAdd(&flags[46], (uint32_t)((z5 - z4) >> 8)); }
+#endif
     if (bad || total_seq == 0) { atomicOr(flags, 1u); cnt[b] = 0; osz[b] = 0; nr[b] = 0; return; }
     Tb[stretches] = SpxPoint{csize, total_seq, total_out};                   // the end, as the last stretch's stop
     cnt[b] = total_seq; osz[b] = total_out; nr[b] = stretches;

@@ -478,7 +478,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 return make_err(LZ4F_ERROR_allocation_failed);
             uint32_t* cnt = (uint32_t*)selfcnt.p; uint32_t* osz = cnt + n_max;
             SpxPoint* spt = (SpxPoint*)spx.p; uint32_t* snr = (uint32_t*)((uint8_t*)spx.p + (size_t)n_max * (SPX_MAXSEG + 1) * sizeof(SpxPoint));
-            HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 64, st));
+            HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 256, st));
             hipLaunchKernelGGL(k_density_probe, dim3(1), dim3(64), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, (uint32_t*)density.p);
             hipLaunchKernelGGL(k_spx_index, dim3(n_max), dim3(128), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, cnt, osz,
                                spt, snr, (uint32_t*)seqcnt.p, sw.no_density_probe ? (const uint32_t*)nullptr : (const uint32_t*)density.p + 1);
@@ -490,6 +490,10 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 HIP_TRY(hipMemcpyAsync(tot, seqcnt.p, sizeof(tot), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
                 if (sw.prof) fprintf(stderr, "spx: flags %u, %u sequences in %u blocks, %u stretches walked by the stitching thread\n", tot[0], tot[9], n_max, tot[2]);
+#ifdef SPX_PROF
+                { uint32_t y[8]; if (hipMemcpy(y, (uint32_t*)seqcnt.p + 48, 32, hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "spx lanes: hit the hop cap %u, without a start %u, started at their segment's first byte %u, ran into something %u; most sequences in one lane %u\n", y[0], y[1], y[2], y[3], y[4]); }
+                { uint32_t z[8]; if (hipMemcpy(z, (uint32_t*)seqcnt.p + 40, 32, hipMemcpyDeviceToHost) == hipSuccess) fprintf(stderr, "spx cycles: guess max %u avg %u, walk max %u avg %u, stitch max %u avg %u, workgroup max %u (waves %u)\n", z[0], (unsigned)(((unsigned long long)z[4] << 8) / (2 * n_max)), z[1], (unsigned)(((unsigned long long)z[5] << 8) / (2 * n_max)), z[2], (unsigned)(((unsigned long long)z[6] << 8) / n_max), z[3], 2 * n_max); }
+#endif
                 if (tot[0] != 0 || tot[9] == 0) break;
                 const void* before = selfix.p;
                 if (selfix.ensure(fixed + (size_t)tot[8] * sizeof(IxEntry) + 64)) return make_err(LZ4F_ERROR_allocation_failed);

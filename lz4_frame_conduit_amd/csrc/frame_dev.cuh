@@ -818,7 +818,7 @@ __global__ __launch_bounds__(64) void k_density_probe(const uint8_t* __restrict_
     uint32_t st = seqs, bt = bytes;
 #pragma unroll
     for (int sft = 1; sft < 64; sft <<= 1) { st += __shfl_xor(st, sft); bt += __shfl_xor(bt, sft); }
-    if (lane == 0) { const bool dense = st != 0 && bt < 24u * st; flags[0] = dense ? 1u : 0u; flags[1] = dense ? 0u : 1u; }
+    if (lane == 0) { const bool dense = st != 0 && bt < 24u * st; flags[0] = dense ? 1u : 0u; flags[1] = dense ? 0u : 1u; flags[2] = st ? bt / st : 0u; }      // [2]: payload bytes per sequence in the sample (0: no sequence seen)
 }
 
 // `hist0`: valid bytes directly in front of dst (streaming API: the previous blocks' last 64 KiB).
