@@ -9,7 +9,7 @@ One "step" = one pass of the hot path over one batch of synthetic input that is 
   decompress  lz4f_mi355x_dev_decompressFrame on those bytes and nothing else: no block table, no side buffer.  It finds the
               trailer, checks it against the frame, parses per index entry, resolves direct matches, copies.
 both through the C ABI on torch's current stream.  The same LZ4 frame WITHOUT its trailer - what a frame from liblz4 or the
-`lz4` tool looks like to this decoder - is timed after the timed region (`foreign_frame`: size-word walk + generic decoder).
+`lz4` tool looks like to this decoder - is timed after the timed region (`foreign_frame`: seeded size-word walk, stretch-parallel self-index, indexed kernels).
 Workload at every N: BASELINE configs[2] per GPU -- 4 GiB of synth50 (~50 % compressible), 4 MiB independent blocks; frame
 blocks are independent, so ranks shard the stream with no data-path collective ("weak" scaling: every rank gets its own 4 GiB
 with seed 1234+rank).  value = bytes of uncompressed input all ranks processed / max-over-ranks wall time of the K steps.
@@ -20,7 +20,7 @@ Extra objects on the JSON line (all outside the timed region):
   kernels        the same for every kernel of the step
   foreign_frame  decode of the bare LZ4 frame (walk included) and its roofline fraction
   block_checksum_on   the step with XXH32 block checksums written and verified on the GPU
-  cfg2           BASELINE configs[1]: decompress-only, 1 GiB of text, 64 KiB independent blocks, bare frame, walk included
+  cfg2           BASELINE configs[1]: decompress-only, 1 GiB of text pre-framed by liblz4 at 64 KiB independent blocks, bare frame, walk included
   host_to_host   lz4f_mi355x_compressFrame / decompressFrame on host buffers (SURVEY 8d variant H), pageable and page-locked
   conduit_replay the reference's conduit call pattern (Conduit.hsc:457-533, :598-701: 16 KiB slices, default preferences)
                  through this library's twelve LZ4F_* functions, next to the CPU codec driven the same way on one thread
@@ -113,8 +113,9 @@ def main():
     ap.add_argument("--linked", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--headline-only", action="store_true", help="skip the side legs: what the rocprofv3 summaries under profiles/ are taken with, so that their per-kernel averages are the headline launches' only")
-    ap.add_argument("--foreign", action="store_true", help="the timed decode gets the bare LZ4 frame (no trailer): walk + generic decoder")
+    ap.add_argument("--foreign", action="store_true", help="the timed decode gets the bare LZ4 frame (no trailer): walk + self-index + indexed kernels")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
+    ap.add_argument("--legs", default="all", help="comma-separated side legs to run (foreign,bck,cfg2,linked,host,replay); what tools/prof_leg.sh profiles one at a time")
     args = ap.parse_args()
 
     # N > 1 and not yet under a launcher: start N ranks (one process per GPU) as a CHILD process and relay its output - nothing in
@@ -210,6 +211,8 @@ def main():
         kt = {**{k: t_c[k] for k in ("find_matches", "layout", "emit", "xxh32_write")}, **{k: t_d[k] for k in ("walk", "xxh32_verify", "decode", "finish", "decode_parse", "decode_copy")}}
 
     side = {}
+    legs = set(x.strip() for x in args.legs.split(","))
+    def want(name): return "all" in legs or name in legs
     if rank == 0 and world == 1 and not args.headline_only:
         algo = float(n + frame_only)
 
@@ -220,15 +223,15 @@ def main():
                 back.zero_()
                 eng.decompress_frame_async(frame, frame_only, back)          # the bare frame: nothing but LZ4
                 rf = eng.result(); tt = eng.get_timing()
-                t.append((tt["walk"] + tt["xxh32_verify"] + tt["decode"] + tt["finish"], tt["walk"], tt["decode"]))
+                t.append((tt["decompress_total"], tt["walk"], tt["decode"]))
                 good = good and bool(rf.size == n and torch.equal(back, src))
             best = min(t)
             return {"what": "the same LZ4 frame without the trailer (as liblz4 / the lz4 tool would have written it), device-resident, no block table: "
-                            "size-word walk + generic fused decoder", "ms": round(best[0], 4), "walk_ms": round(best[1], 4), "decode_ms": round(best[2], 4),
+                            "seeded size-word walk, then the decoder cuts the blocks into stretches itself (decode_spx.cuh) and runs the indexed kernels", "ms": round(best[0], 4), "walk_ms": round(best[1], 4), "decode_ms": round(best[2], 4),
                     "roundtrip_verified": good,
                     "roofline": {"bound": "hbm", "achieved": round(algo / (best[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(algo / (best[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
-        side["foreign_frame"] = leg(foreign)
+        if want("foreign"): side["foreign_frame"] = leg(foreign)
 
         def bck_on():
             p2 = conduit.make_preferences(blockSizeID=args.block_size_id, blockMode=1, blockChecksum=1)
@@ -239,40 +242,69 @@ def main():
                 back.zero_()
                 eng.decompress_frame_async(frame, int(rr.size), back); rd = eng.result(); td = eng.get_timing()
                 good = good and bool(rd.size == n and torch.equal(back, src))
-                ms = sum(tc[k] for k in ("find_matches", "layout", "emit", "xxh32_write")) + sum(td[k] for k in ("walk", "xxh32_verify", "decode", "finish"))
+                ms = tc["compress_total"] + td["decompress_total"]          # (whole calls: the verification runs beside the decode kernels, on a stream of its own)
                 if best is None or ms < best[0]:
-                    best = (ms, tc["xxh32_write"], td["xxh32_verify"])
-            return {"what": "the headline step with an XXH32 behind every block, written and verified on the GPU (a 4 MiB block is one serial chain for one wave)",
+                    best = (ms, tc["xxh32_write"], td["xxh32_verify"], tc["compress_total"], td["decompress_total"])
+            return {"what": "the headline step with an XXH32 behind every block, written and verified on the GPU (a 4 MiB block is one serial chain for one wave: ~2 ms "
+                            "whatever else runs; the verification runs beside the decode kernels, the writing can only follow the last block's emission)",
                     "ms_per_step": round(best[0], 3), "xxh32_write_ms": round(best[1], 3), "xxh32_verify_ms": round(best[2], 3),
+                    "compress_ms": round(best[3], 3), "decompress_ms": round(best[4], 3),
                     "e2e_GiBs": round(n / (best[0] * 1e-3) / GIB, 1), "roundtrip_verified": good}
-        side["block_checksum_on"] = leg(bck_on)
+        if want("bck"): side["block_checksum_on"] = leg(bck_on)
 
         def cfg2():
-            m = 1 << 30
-            tx = torch.from_numpy(datagen.synth_text(64 << 20, 99)).to(dev).repeat(m // (64 << 20))
-            p2 = conduit.make_preferences(blockSizeID=4, blockMode=1)
-            f2 = torch.empty(eng.frame_bound(m, p2), dtype=torch.uint8, device=dev)
-            eng.compress_async(tx, f2, p2); rc = eng.result(); tc = eng.get_timing()
+            # BASELINE configs[1]: "1 GiB enwik-style text pre-framed at 64 KiB independent blocks" - pre-framed by liblz4 (the reference's
+            # codec): LZ4F_compressFrame of a 64 MiB tile of the text through the installed liblz4.so.1, or - where that is absent - through
+            # the oracle port, which is bit-exact with it; the tile's blocks, sixteen times, between one header and one EndMark.
+            m, tile_n = 1 << 30, 64 << 20
+            tile = datagen.synth_text(tile_n, 99)
+            framer = None
+            try:
+                lz = ctypes.CDLL("liblz4.so.1")
+                lz.LZ4F_compressFrameBound.restype = ctypes.c_size_t; lz.LZ4F_compressFrameBound.argtypes = [ctypes.c_size_t, ctypes.c_void_p]
+                lz.LZ4F_compressFrame.restype = ctypes.c_size_t; lz.LZ4F_compressFrame.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+                lp = conduit.make_preferences(blockSizeID=4, blockMode=1)
+                cap = lz.LZ4F_compressFrameBound(tile_n, ctypes.byref(lp))
+                buf = ctypes.create_string_buffer(cap)
+                r_ = lz.LZ4F_compressFrame(buf, cap, tile.ctypes.data_as(ctypes.c_void_p), tile_n, ctypes.byref(lp))
+                if r_ < 64 or r_ > cap: raise OSError("LZ4F_compressFrame: %d" % r_)
+                one = buf.raw[:r_]; framer = "liblz4.so.1 %d (LZ4F_compressFrame)" % lz.LZ4_versionNumber()
+            except (OSError, AttributeError):
+                import oracle
+                one = oracle.conduit_compress(tile.tobytes(), oracle.mkprefs(bsid=4, indep=1)); framer = "oracle port of liblz4 1.9.3 (bit-exact with it: tests/test_oracle_golden.py)"
+            assert one[:4] == b"\x04\x22\x4d\x18" and one[-4:] == bytes(4) and len(one) > 11
+            body = np.frombuffer(one[7:-4], dtype=np.uint8)
+            reps = m // tile_n
+            host = np.empty(7 + len(body) * reps + 4 + 64, dtype=np.uint8)
+            host[:7] = np.frombuffer(one[:7], dtype=np.uint8)
+            for r_ in range(reps): host[7 + r_ * len(body): 7 + (r_ + 1) * len(body)] = body
+            fsize = 7 + len(body) * reps + 4
+            host[fsize - 4:] = 0
+            f2 = torch.from_numpy(host).to(dev)
+            tx = torch.from_numpy(tile).to(dev).repeat(reps)
             b2 = torch.empty(m, dtype=torch.uint8, device=dev)
             best = None
             good = True
             for _ in range(3):
                 b2.zero_()
-                eng.decompress_frame_async(f2, int(rc.size), b2); rd = eng.result(); td = eng.get_timing()
-                good = good and bool(rd.size == m and torch.equal(b2, tx))
-                ms = td["walk"] + td["decode"] + td["finish"]
+                eng.decompress_frame_async(f2, fsize, b2); rd = eng.result(); td = eng.get_timing()
+                good = good and bool(rd.size == m and rd.consumed == fsize and torch.equal(b2, tx))
+                ms = td["decompress_total"]
                 if best is None or ms < best[0]:
                     best = (ms, td["walk"], td["decode"])
-            a2 = float(m + int(rc.size))
-            return {"workload": "BASELINE configs[1]: decompress-only, 1 GiB of synthetic text (Zipf words, ratio %.2f), 64 KiB independent blocks, bare LZ4 frame "
-                                "(this library's encoder, no trailer), device-resident, no block table" % (m / int(rc.size)),
+            a2 = float(m + fsize)
+            # this library's own encoder on the same text, for the record (not what the leg decodes)
+            p2 = conduit.make_preferences(blockSizeID=4, blockMode=1)
+            f3 = torch.empty(eng.frame_bound(m, p2), dtype=torch.uint8, device=dev)
+            eng.compress_async(tx, f3, p2); rc = eng.result(); tc = eng.get_timing()
+            return {"workload": "BASELINE configs[1]: decompress-only, 1 GiB of synthetic text (Zipf words, liblz4 ratio %.3f), pre-framed at 64 KiB independent blocks by %s, bare LZ4 frame, "
+                                "device-resident, no block table" % (m / fsize, framer),
                     "decompress_ms": round(best[0], 3), "walk_ms": round(best[1], 3), "decode_ms": round(best[2], 3),
                     "decompress_GiBs": round(m / (best[0] * 1e-3) / GIB, 1), "roundtrip_verified": good,
-                    "compress_ms": round(tc["find_matches"] + tc["layout"] + tc["emit"], 3),
-                    "compress_GiBs": round(m / ((tc["find_matches"] + tc["layout"] + tc["emit"]) * 1e-3) / GIB, 1),
+                    "own_encoder": {"compress_ms": round(tc["compress_total"], 3), "compress_GiBs": round(m / (tc["compress_total"] * 1e-3) / GIB, 1), "ratio": round(m / int(rc.size), 4)},
                     "roofline": {"bound": "hbm", "achieved": round(a2 / (best[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(a2 / (best[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
-        side["cfg2"] = leg(cfg2)
+                                 "frac": round(a2 / (best[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(a2)}}
+        if want("cfg2"): side["cfg2"] = leg(cfg2)
 
         def linked_default():
             m = 1 << 30
@@ -291,7 +323,7 @@ def main():
                     best = (c_ms, d_ms)
             return {"workload": "1 GiB of the same stream, 64 KiB LINKED blocks (Conduit.hsc default preferences), device-resident, decoded from the stream alone",
                     "compress_ms": round(best[0], 3), "decompress_ms": round(best[1], 3), "e2e_GiBs": round(m / ((best[0] + best[1]) * 1e-3) / GIB, 1), "roundtrip_verified": good}
-        side["reference_default_framing"] = leg(linked_default)
+        if want("linked"): side["reference_default_framing"] = leg(linked_default)
 
         def host_legs():
             L = _ffi.lib()
@@ -334,7 +366,7 @@ def main():
                 g = m / GIB
                 out[mode] = {"compress_GiBs": round(g / bc, 2), "decompress_GiBs": round(g / bd, 2), "round_trip_GiBs": round(g / (bc + bd), 2), "roundtrip_verified": good}
             return out
-        side["host_to_host"] = leg(host_legs)
+        if want("host"): side["host_to_host"] = leg(host_legs)
 
         def conduit_replay():
             import oracle
@@ -352,7 +384,7 @@ def main():
                             "this library's twelve LZ4F_* functions (one block per call: upload, 4 launches, download) vs the CPU codec (oracle port, 1 thread) driven the same way",
                     "gpu_library": {"compress_GiBs": round(g / (t1_ - t0_), 3), "decompress_GiBs": round(g / (t3_ - t2_), 3), "roundtrip_verified": good},
                     "cpu_1_thread": {"compress_GiBs": round(g / (t5_ - t4_), 3), "decompress_GiBs": round(g / (t7_ - t6_), 3), "kind": "port", "roundtrip_verified": rb == data}}
-        side["conduit_replay"] = leg(conduit_replay)
+        if want("replay"): side["conduit_replay"] = leg(conduit_replay)
 
     if rank == 0:
         total_u = n * world * args.steps
@@ -372,7 +404,7 @@ def main():
             "config": {"workload": "synth50 (~50%% compressible), %.0f GiB per GPU per step, %d KiB %s blocks, device-resident (inputs/outputs in HBM), "
                                    "block checksums %s, content checksum off, decode from the byte stream alone (%s)" % (
                                        n / GIB, bs >> 10, "linked" if args.linked else "independent", "on" if args.block_checksum else "off",
-                                       "bare LZ4 frame: size-word walk + generic decoder" if args.foreign else
+                                       "bare LZ4 frame: seeded size-word walk + stretch-parallel self-index + indexed kernels" if args.foreign else
                                        "the compressor's index travels in the stream as a skippable frame behind the LZ4 frame; no block table, no side buffer"),
                        "bytes_per_gpu": n, "block_size": bs, "n_blocks_per_gpu": nb, "generator": "synth50 recipe, torch Philox seed 1234+rank",
                        "sharding": ("BASELINE configs[3] shape: %d ranks x %.0f GiB = %.0f GiB of synth50 per step, every rank its own stream (seed 1234+rank) of %d "

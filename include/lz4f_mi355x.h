@@ -212,8 +212,10 @@ LZ4F_MI355X_API size_t lz4f_mi355x_engine_set_deterministic(lz4f_mi355x_engine* 
  * compress / decompress call.  get_timing synchronises the stream and fills ms[] (milliseconds):
  *   [0] find_matches  [1] layout  [2] emit  [3] xxh32 (compress)  [4] walk  [5] xxh32 (verify)  [6] decode (all kernels)
  *   [7] finish  [8] decode: parse kernel  [9] decode: copy kernel
+ *   [10] the whole compress call  [11] the whole decompress call (first kernel's start to last kernel's end on the engine's stream:
+ *        the block-checksum verification runs beside the decode kernels on a stream of the engine's own, so [5] + [6] > [11])
  * entries of kernels that did not run are 0. */
-#define LZ4F_MI355X_TIMING_SLOTS 10
+#define LZ4F_MI355X_TIMING_SLOTS 12
 LZ4F_MI355X_API size_t lz4f_mi355x_engine_set_timing(lz4f_mi355x_engine* e, int enable);
 LZ4F_MI355X_API size_t lz4f_mi355x_engine_get_timing(lz4f_mi355x_engine* e, float* ms);
 

@@ -85,7 +85,7 @@ void lz4f_mi355x_engine::Switches::read()
     no_index = on("LZ4F_MI355X_NO_INDEX"); no_selfindex = on("LZ4F_MI355X_NO_SELFINDEX"); no_resolve = on("LZ4F_MI355X_NO_RESOLVE");
     no_trace = on("LZ4F_MI355X_NO_TRACE"); no_doubling = on("LZ4F_MI355X_NO_DOUBLING"); trace_always = on("LZ4F_MI355X_TRACE_ALWAYS");
     no_groups = on("LZ4F_MI355X_NO_GROUPS"); no_window = on("LZ4F_MI355X_NO_WINDOW"); serial_walk = on("LZ4F_MI355X_SERIAL_WALK");
-    no_trailer = on("LZ4F_MI355X_NO_TRAILER"); no_density_probe = on("LZ4F_MI355X_NO_DENSITY_PROBE"); no_spx = on("LZ4F_MI355X_NO_SPX"); no_content_check = on("LZ4F_MI355X_NO_CONTENT_CHECK"); prof = on("LZ4F_MI355X_PROF"); e1_sync = on("LZ4F_MI355X_E1_SYNC");
+    no_trailer = on("LZ4F_MI355X_NO_TRAILER"); no_density_probe = on("LZ4F_MI355X_NO_DENSITY_PROBE"); no_spx = on("LZ4F_MI355X_NO_SPX"); no_overlap = on("LZ4F_MI355X_NO_OVERLAP"); no_content_check = on("LZ4F_MI355X_NO_CONTENT_CHECK"); prof = on("LZ4F_MI355X_PROF"); e1_sync = on("LZ4F_MI355X_E1_SYNC");
     chain_gate = 0; if (const char* v = getenv("LZ4F_MI355X_CHAIN_GATE")) { const int g = atoi(v); if (g > 0 && g < (1 << 20)) chain_gate = g; }
     decode_mode = 0; if (const char* v = getenv("LZ4F_MI355X_DECODE")) decode_mode = v[0];
     e1_run = 0; if (const char* v = getenv("LZ4F_MI355X_E1_RUN")) { const int g = atoi(v); if (g >= 1 && g <= 4096) e1_run = (unsigned)g; }
@@ -168,17 +168,29 @@ lz4f_mi355x_engine::~lz4f_mi355x_engine()
     info.release(); recs.release(); e1_scratch.release(); walkbuf.release(); density.release(); ixtmp.release(); table.release(); blk_bytes.release(); res.release(); bad.release();
     d_in.release(); d_out.release();
     h_in.release(); h_out.release(); h_small.release();
-    for (int i = 0; i < 20; i++) if (ev[i]) (void)hipEventDestroy((hipEvent_t)ev[i]);
+    for (int i = 0; i < 24; i++) if (ev[i]) (void)hipEventDestroy((hipEvent_t)ev[i]);
+    if (aux_stream) { (void)hipStreamSynchronize((hipStream_t)aux_stream); (void)hipStreamDestroy((hipStream_t)aux_stream); }
+    if (ev_fork) (void)hipEventDestroy((hipEvent_t)ev_fork);
+    if (ev_join) (void)hipEventDestroy((hipEvent_t)ev_join);
     if (own_stream && stream) (void)hipStreamDestroy((hipStream_t)stream);
 }
 
-void lz4f_mi355x_engine::tick(int slot, bool end)
+void lz4f_mi355x_engine::tick(int slot, bool end, void* on_stream)
 {
     if (!timing) return;
     const int i = slot * 2 + (end ? 1 : 0);
     if (!ev[i]) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) return; ev[i] = e; }
-    (void)hipEventRecord((hipEvent_t)ev[i], (hipStream_t)stream);
+    (void)hipEventRecord((hipEvent_t)ev[i], (hipStream_t)(on_stream ? on_stream : stream));
     if (end) ev_used[slot] = true;
+}
+bool lz4f_mi355x_engine::aux_ready()
+{
+    if (aux_stream && ev_fork && ev_join) return true;
+    hipStream_t s; hipEvent_t a, b;
+    if (!aux_stream) { if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return false; } aux_stream = s; }
+    if (!ev_fork) { if (hipEventCreateWithFlags(&a, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; } ev_fork = a; }
+    if (!ev_join) { if (hipEventCreateWithFlags(&b, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; } ev_join = b; }
+    return true;
 }
 
 size_t lz4f_mi355x_engine::sync()
@@ -243,6 +255,8 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
 
     constexpr int W = 4;
     for (int i = 0; i < 4; i++) ev_used[i] = false;
+    ev_used[10] = false;
+    tick(10, false);
     if (g.n_chunks) {
         tick(0, false);
         {
@@ -303,6 +317,7 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
                            (uint64_t)ix_entries_at(g.n_blocks, g.chunks_per_block), plan);
         hipLaunchKernelGGL(k_trailer_copy, dim3(256), dim3(256), 0, st, d_dst, (const TrailerPlan*)plan, (const BlockOut*)d_table, g.n_blocks, (const void*)d_index);
     }
+    tick(10, true);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -317,6 +332,9 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
     uint32_t n_max;
     uint32_t plan = 0;                                               // LZ4F_MI355X_PATH_*: reported in result.flags
     for (int i = 4; i < 10; i++) ev_used[i] = false;
+    ev_used[11] = false;
+    if (aux_pending) { HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0)); aux_pending = false; }      // (a call that left early: its forked work first)
+    tick(11, false);
     if (j.d_table || j.table_in_place) {
         // caller-supplied table: work on a copy (decode overwrites dst_size)
         n_max = j.n_blocks;
@@ -398,13 +416,21 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
     const uint32_t* ix_flags = nullptr;                              // the indexed kernels' "gave up" word, if they were launched
     if (n_max) {
         if (j.block_checksum) {
-            tick(5, false);
+            // The verification only reads the payloads, and so do the decode kernels: it runs beside them on the engine's second stream
+            // (forked here, joined in front of k_finish_check, which reads its verdict).  A 4 MiB block is one serial chain for one wave
+            // (~2 ms) whatever else the GPU does, so side by side the two cost max(2.0, decode) instead of the sum.  The one-wave
+            // workgroups then ask for 12 KiB of LDS instead of 36 (they would not fit beside four decode workgroups per CU).
+            const bool beside = !sw.no_overlap && aux_ready();
+            hipStream_t xs = beside ? (hipStream_t)aux_stream : st;
+            if (beside) { HIP_TRY(hipEventRecord((hipEvent_t)ev_fork, st)); HIP_TRY(hipStreamWaitEvent(xs, (hipEvent_t)ev_fork, 0)); }
+            tick(5, false, xs);
             if (n_max < XXH_LANE4_BELOW)
-                hipLaunchKernelGGL((k_xxh32_blocks4<1>), dim3(n_max), dim3(64), XXH_SPREAD_LDS, st, (uint8_t*)j.d_frame, tbl, (const ResultRec*)d_res, n_max, 1u, (uint32_t*)bad.p);
+                hipLaunchKernelGGL((k_xxh32_blocks4<1>), dim3(n_max), dim3(64), beside ? (12u << 10) : XXH_SPREAD_LDS, xs, (uint8_t*)j.d_frame, tbl, (const ResultRec*)d_res, n_max, 1u, (uint32_t*)bad.p);
             else
-            hipLaunchKernelGGL((k_xxh32_blocks<W>), dim3((n_max + W - 1) / W), dim3(64 * W), 0, st, (uint8_t*)j.d_frame, tbl,
+            hipLaunchKernelGGL((k_xxh32_blocks<W>), dim3((n_max + W - 1) / W), dim3(64 * W), 0, xs, (uint8_t*)j.d_frame, tbl,
                                (const ResultRec*)d_res, n_max, 1u, (uint32_t*)bad.p);
-            tick(5, true);
+            tick(5, true, xs);
+            if (beside) { HIP_TRY(hipEventRecord((hipEvent_t)ev_join, xs)); aux_pending = true; }
         }
         tick(6, false);
         // large blocks / linked frames: fused parse+copy workgroups ('f'); small independent blocks: one wave per block ('1')
@@ -672,6 +698,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         }
         tick(6, true);
     }
+    if (aux_pending) { HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0)); aux_pending = false; }
     tick(7, false);
     if (n_max) hipLaunchKernelGGL(k_finish_check, dim3((n_max + 255) / 256), dim3(256), 0, st, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, (uint32_t*)bad.p);
     hipLaunchKernelGGL(k_finish_decode, dim3(1), dim3(64), 0, st, j.d_dst, tbl, (ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size,
@@ -679,6 +706,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
     if (j.content_checksum && !j.d_table && !j.table_in_place && !sw.no_content_check)      // (a whole frame was walked: res->consumed is behind its checksum word)
         hipLaunchKernelGGL(k_xxh32_content, dim3(1), dim3(64), 0, st, (const uint8_t*)j.d_dst, 0ull, (uint8_t*)j.d_frame, (ResultRec*)d_res, 1u);
     tick(7, true);
+    tick(11, true);
     HIP_TRY(hipGetLastError());
     return 0;
 }

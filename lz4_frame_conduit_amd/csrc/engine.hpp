@@ -68,15 +68,20 @@ struct lz4f_mi355x_engine {
     // A-B and development switches: read from the environment ONCE, when the engine is made (engines of the host-pointer calls
     // live in a pool: lz4f_mi355x_release_engines() makes the next ones read it again)
     struct Switches {
-        bool no_index, no_selfindex, no_resolve, no_trace, no_doubling, trace_always, no_groups, no_window, serial_walk, no_trailer, no_content_check, no_density_probe, no_spx, prof, e1_sync;
+        bool no_index, no_selfindex, no_resolve, no_trace, no_doubling, trace_always, no_groups, no_window, serial_walk, no_trailer, no_content_check, no_density_probe, no_spx, no_overlap, prof, e1_sync;
         int chain_gate; char decode_mode; unsigned e1_run, e1_solo, seed; unsigned long long wait_ticks;
         void read();
     } sw;
     size_t ix_seq_cap = 0;                                 // indexed decode: descriptor workspace, in sequences (grow-only)
     bool  timing = false;
-    void* ev[20] = {nullptr};      // hipEvent_t pairs (begin,end) per timing slot
-    bool  ev_used[10] = {false};
-    void  tick(int slot, bool end);
+    void* ev[24] = {nullptr};      // hipEvent_t pairs (begin,end) per timing slot
+    bool  ev_used[12] = {false};
+    void  tick(int slot, bool end, void* on_stream = nullptr);
+    // a second stream of the engine's own: work that only reads what the main stream's kernels read (block-checksum verification beside
+    // the decode) is forked onto it and joined before the verdict (fork / join: events between the two streams, nothing on the host)
+    void* aux_stream = nullptr; void* ev_fork = nullptr; void* ev_join = nullptr;
+    bool  aux_ready();
+    bool  aux_pending = false;     // work forked onto aux_stream that the main stream has not waited for yet
 
     // ---- device-pointer paths (asynchronous on `stream`) ----
     struct CompressJob {

@@ -46,7 +46,7 @@ class Engine:
         except Exception:
             pass
 
-    TIMING_SLOTS = ("find_matches", "layout", "emit", "xxh32_write", "walk", "xxh32_verify", "decode", "finish", "decode_parse", "decode_copy")
+    TIMING_SLOTS = ("find_matches", "layout", "emit", "xxh32_write", "walk", "xxh32_verify", "decode", "finish", "decode_parse", "decode_copy", "compress_total", "decompress_total")
 
     def set_deterministic(self, on: bool):
         """Equal input -> equal bytes (one wave per workgroup parses, in order); about a tenth of the match finder's speed."""
@@ -56,7 +56,7 @@ class Engine:
         _chk(self.L, self.L.lz4f_mi355x_engine_set_timing(self.h, 1 if on else 0))
 
     def get_timing(self) -> dict:
-        ms = (ctypes.c_float * 10)()
+        ms = (ctypes.c_float * 12)()
         _chk(self.L, self.L.lz4f_mi355x_engine_get_timing(self.h, ms))
         return dict(zip(self.TIMING_SLOTS, [float(x) for x in ms]))
 
