@@ -92,6 +92,7 @@ void lz4f_mi355x_engine::Switches::read()
     e1_solo = 0; if (const char* v = getenv("LZ4F_MI355X_E1_SOLO")) e1_solo = (unsigned)atoi(v);
     if (on("LZ4F_MI355X_DETERMINISTIC")) e1_solo |= 1u;              // equal input -> equal bytes: one wave per workgroup parses, in order (see lz4f_mi355x_engine_set_deterministic)
     wait_ticks = 0; if (const char* v = getenv("LZ4F_MI355X_WAIT_TICKS")) { unsigned long long a = 0; if (sscanf(v, "%llu", &a) == 1) wait_ticks = a; }
+    dblk_lds = 0; if (const char* v = getenv("LZ4F_MI355X_DBLK_LDS")) { const int k = atoi(v); if (k > 0 && k <= 150) dblk_lds = (unsigned)k << 10; }      // (development: fewer wave-per-block decoders per CU)
     seed = 2; if (const char* v = getenv("LZ4F_MI355X_SEED")) { unsigned a = 0; if (sscanf(v, "%u", &a) == 1 && a >= 1 && a <= 64) seed = a; }
 }
 namespace lz4f {
@@ -693,7 +694,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                                    (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, j.hist0, prof, only_if);
         } else {
             plan |= LZ4F_MI355X_PATH_WAVE_PER_BLOCK;
-            hipLaunchKernelGGL((k_decode_blocks<W>), dim3(grid), dim3(64 * W), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl, (const ResultRec*)d_res,
+            hipLaunchKernelGGL((k_decode_blocks<W>), dim3(grid), dim3(64 * W), sw.dblk_lds, st, j.d_frame, j.d_dst, j.dst_cap, tbl, (const ResultRec*)d_res,
                                n_max, j.linked ? 1u : 0u, j.block_size, j.hist0, (uint64_t)j.frame_cap);
         }
         tick(6, true);
