@@ -344,6 +344,8 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         if (!j.table_in_place)
             HIP_TRY(hipMemcpyAsync(tbl, j.d_table, (size_t)n_max * sizeof(BlockOut), hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_init_result, dim3(1), dim3(64), 0, st, (ResultRec*)d_res, n_max, 0u);
+        if (n_max) hipLaunchKernelGGL(k_check_table, dim3(std::min<uint32_t>((n_max + 255) / 256, 1024u)), dim3(256), 0, st, (const BlockOut*)tbl, n_max, (uint64_t)j.frame_cap, (uint64_t)j.dst_cap,
+                                      j.block_size, j.block_checksum ? 1u : 0u, j.linked ? 1u : 0u, (ResultRec*)d_res);
         plan |= LZ4F_MI355X_PATH_TABLE_GIVEN;
     } else {
         n_max = j.max_blocks;

@@ -781,6 +781,26 @@ __global__ void k_init_result(ResultRec* res, uint32_t n_blocks, uint32_t flags)
         res->size = 0; res->consumed = 0; res->status = ST_OK; res->n_blocks = n_blocks; res->first_bad_block = 0xFFFFFFFFu; res->flags = flags;
     }
 }
+// A block table that came from the caller (lz4f_mi355x_dev_decompressBlocks / ...Indexed): every entry inside the frame and the output
+// buffer, and the entries in order without overlap on either side - the blocks are decoded concurrently, so two entries that share output
+// bytes would be a race, and entries that share frame bytes are not a walk of any frame.  A table that fails gets ERROR_GENERIC and
+// first_bad_block; nothing is decoded (every decode kernel returns at once on a result that is not OK).
+__global__ __launch_bounds__(256) void k_check_table(const BlockOut* __restrict__ table, uint32_t n, uint64_t frame_cap, uint64_t dst_cap, uint32_t block_size,
+                                                     uint32_t bck, uint32_t linked, ResultRec* __restrict__ res)
+{
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const BlockOut e = table[i];
+        const uint64_t csz = e.word & 0x7FFFFFFFu;
+        bool bad = csz > block_size || e.src_off > frame_cap || frame_cap - e.src_off < csz + 4ull * bck;
+        bad = bad || e.dst_off > dst_cap || e.dst_size > block_size || (!linked && dst_cap - e.dst_off < e.dst_size);
+        if (!bad && i + 1 < n) {
+            const BlockOut x = table[i + 1];
+            bad = x.src_off < e.src_off + csz + 4ull * bck + 4ull;                           // (the next payload lies behind this one, its checksum and the next size word)
+            if (!linked) bad = bad || x.dst_off < e.dst_off + e.dst_size;                    // (linked frames: positions are the decoder's, packed as it goes)
+        }
+        if (bad) { atomicMin(&res->first_bad_block, i); atomicMax(&res->status, (uint32_t)ST_GENERIC); }
+    }
+}
 __global__ void k_set_block(BlockOut* t, BlockOut e) { if (threadIdx.x == 0 && blockIdx.x == 0) *t = e; }
 
 // Which decoder for a frame of big independent blocks that came without a usable index?  The fused workgroups parse on the scalar

@@ -864,6 +864,45 @@ def test_inband_trailer_interop_and_robustness(L):
 
 
 @pytest.mark.gpu
+def test_caller_block_table_is_validated(L):
+    """lz4f_mi355x_dev_decompressBlocks takes the caller's block table.  Its entries are decoded concurrently, so the device checks them
+    against each other before anything runs: in order, inside the frame and the output buffer, no two sharing frame or output bytes.
+    A table that fails is refused (ERROR_GENERIC, first_bad_block) and the output is not touched."""
+    import torch
+    from lz4_frame_conduit_amd.device import Engine, DeviceCodecError
+    from lz4_frame_conduit_amd._ffi import Block
+    eng = Engine(0)
+    data = datagen.synth50(20 << 20, 9)
+    src = torch.from_numpy(data).cuda()
+    p = prefs_of(dict(bsid=7, indep=1))
+    nb = 5
+    frame = torch.empty(eng.frame_bound(src.numel(), p), dtype=torch.uint8, device="cuda")
+    table = eng.new_table(nb)
+    eng.compress_async(src, frame, p, table)
+    r = eng.result()
+    back = torch.zeros_like(src)
+    eng.decompress_blocks_async(frame, r.size, back, table, nb, p.frameInfo); assert eng.result().size == src.numel() and torch.equal(back, src)
+    host = table.cpu().numpy().copy()
+    ent = np.frombuffer(host.tobytes(), dtype=np.dtype([("src_off", "<u8"), ("dst_off", "<u8"), ("word", "<u4"), ("dst_size", "<u4")]))[:nb + 1].copy()
+    def attempt(mut):
+        e2 = ent.copy(); mut(e2)
+        t2 = torch.from_numpy(np.frombuffer(e2.tobytes(), dtype=np.uint8).copy()).cuda()
+        out = torch.full_like(src, 0x5A)
+        eng.decompress_blocks_async(frame, r.size, out, t2, nb, p.frameInfo)
+        with pytest.raises(DeviceCodecError): eng.result()
+        assert bool((out == 0x5A).all()), "a refused table must not have written anything"
+    def swap(e): e[[1, 2]] = e[[2, 1]]
+    def same_out(e): e["dst_off"][3] = e["dst_off"][2]
+    def overlap_out(e): e["dst_off"][2] -= 4096
+    def overlap_in(e): e["src_off"][3] = e["src_off"][2] + 100
+    def past_frame(e): e["src_off"][4] = int(r.size) + (1 << 20)
+    def past_out(e): e["dst_off"][4] = src.numel() - 100
+    def huge_word(e): e["word"][1] = (8 << 20)
+    for m in (swap, same_out, overlap_out, overlap_in, past_frame, past_out, huge_word): attempt(m)
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_deterministic_encoder_mode(L):
     """liblz4 maps equal input to equal bytes; the default encoder here does not (sixteen waves race for hash slots: sizes differ by
     ~1e-5 between runs, every frame valid).  lz4f_mi355x_engine_set_deterministic / LZ4F_MI355X_DETERMINISTIC=1: one wave per
