@@ -421,7 +421,7 @@ def test_structured_inputs_both_directions(L):
     # wave gets there first differs from run to run, so does the size).  The ratio bar of the parity configs (RATIO_TOL) is
     # checked on their inputs above; here only a sanity bound.
     print("worst size ratio vs liblz4 on structured inputs: %.3f (seed %d, %s)" % worst)
-    assert worst[0] <= 1.40, worst
+    assert worst[0] <= 1.32, worst          # measured 1.228 .. 1.255 over runs (round 3, seed 11: a 9 MiB input of short-period runs), + 5 %
 
 
 # ------------------------------------------------------------------------------------------------
@@ -861,6 +861,26 @@ def test_inband_trailer_interop_and_robustness(L):
             r3 = eng.result()
             assert r3.size == src.numel() and torch.equal(back, src), (name, trial)
     eng.close()
+
+
+@pytest.mark.gpu
+def test_soak_and_fuzz_slices():
+    """A slice of the development soak (tools/soak_indexed.py: random shapes compressed, then decoded with, without and again with the
+    index) and of the mutation fuzz (tools/fuzz_linked.py: single-byte mutations, verdicts and bytes against the oracle) on every run
+    of the GPU tests: the encoder's waves race for hash slots, so intermittent failures are the realistic kind, and a fixed case list
+    does not find them.  Seeds change from run to run (printed on failure); each tool runs in a child process with a time limit."""
+    import subprocess, time
+    seed = int(time.time()) % 100000
+    env = dict(os.environ)
+    jobs = [([sys.executable, os.path.join(ROOT, "tools", "soak_indexed.py"), "14", str(seed)], {}),
+            ([sys.executable, os.path.join(ROOT, "tools", "fuzz_linked.py"), str(seed), "50"], {}),                                   # linked 64 KiB (self-index, window kernel)
+            ([sys.executable, os.path.join(ROOT, "tools", "fuzz_linked.py"), str(seed + 1), "40"], {"INDEP": "1", "BSID": "7"}),      # big independent blocks (density probe, stretches)
+            ([sys.executable, os.path.join(ROOT, "tools", "fuzz_linked.py"), str(seed + 2), "40"], {"INDEP": "1", "BSID": "4"}),      # small independent blocks (lanes find the tokens)
+            ([sys.executable, os.path.join(ROOT, "tools", "fuzz_linked.py"), str(seed + 3), "40"], {"DATA": "text"})]                 # dense linked frame (pointer doubling)
+    for cmd, extra in jobs:
+        e = dict(env); e.update(extra)
+        r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (cmd[1:], extra, r.stdout[-600:], r.stderr[-300:])
 
 
 @pytest.mark.gpu

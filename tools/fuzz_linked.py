@@ -29,3 +29,4 @@ for i in range(n_mut):
     if (ov == "ok") != (gv == "ok") or (ov == "ok" and dst.raw[:r] != want):
         diff += 1; print("pos", pos, "xor", x, "oracle", ov, "gpu", gv)
 print("mutations", n_mut, "verdict differences", diff, "seconds %.1f" % (time.time() - t0))
+sys.exit(1 if diff else 0)
