@@ -662,7 +662,9 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             const bool small = !j.linked && j.block_size <= (1u << 20);
             // a linked frame is one chain: one workgroup with the 64 KiB window in LDS; frames with short (flushed) blocks
             // set the flag and are decoded by the generic kernel launched right behind (it returns at once otherwise)
-            const bool windowed = j.linked && j.dst_cap < 0xFFF00000ull && !sw.no_window;
+            // (one block of a linked frame - what the streaming functions hand over per call: the window kernel is built for whole frames
+            // and takes 180-210 us for a single 64 KiB block; the fused workgroup takes it directly)
+            const bool windowed = j.linked && j.dst_cap < 0xFFF00000ull && !sw.no_window && !(n_max == 1 && (j.d_table || j.table_in_place));
             const uint32_t* only_if = indexed ? (const uint32_t*)seqcnt.p : nullptr;      // behind the indexed kernels the generic ones only run if they gave up
             if (windowed) {
                 plan |= LZ4F_MI355X_PATH_WINDOW;
@@ -822,6 +824,38 @@ size_t lz4f_mi355x_engine::slab_compress(const uint8_t* src, size_t n, const uin
     HIP_TRY(hipStreamSynchronize(st));
     if (hr->status != ST_OK) { set_last_error("device compress status %u", hr->status); return make_err((int)hr->status); }
     *size = hr->size;
+    return 0;
+}
+
+size_t lz4f_mi355x_engine::compress_block_pinned(const uint8_t* pin_src, size_t hist_len, size_t n, uint32_t block_size, bool linked, bool block_checksum,
+                                                 uint8_t* pin_dst, size_t dst_cap, void* pin_res, size_t* size)
+{
+    // (Kernels reading the staging buffer through the link themselves - no copies at all - were tried first: 510 us per 64 KiB block
+    // against 190 us with copies.  A kernel's scattered 16-byte reads over PCIe are not what a DMA engine's are.)
+    *size = 0;
+    if (n == 0) return 0;
+    HIP_TRY(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    if (!linked) hist_len = 0;
+    const size_t total = hist_len + n;
+    const size_t out_cap = n + ((n + block_size - 1) / block_size) * 8 + 64;
+    const size_t res_at = (out_cap + 63) & ~(size_t)63;                  // the result record rides behind the blocks: one copy back
+    if (out_cap > dst_cap) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
+    if (d_in.ensure(total + 64) || d_out.ensure(res_at + sizeof(ResultRec) + 64)) return make_err(LZ4F_ERROR_allocation_failed);
+    HIP_TRY(hipMemcpyAsync(d_in.p, pin_src, total, hipMemcpyHostToDevice, st));
+    CompressJob j; memset(&j, 0, sizeof(j));
+    j.d_src = (const uint8_t*)d_in.p; j.src_size = total; j.first_off = hist_len; j.block_size = block_size;
+    j.linked = linked; j.block_checksum = block_checksum; j.endmark = false; j.header_size = 0;
+    lz4f_mi355x_result* d_res = (lz4f_mi355x_result*)((uint8_t*)d_out.p + res_at);
+    size_t r = launch_compress(j, (uint8_t*)d_out.p, out_cap, d_res, nullptr);
+    if (is_err(r)) return r;
+    // (the blocks' size is not known on the host yet: everything up to the record comes back - at most a block and a few bytes)
+    HIP_TRY(hipMemcpyAsync(pin_dst, d_out.p, res_at + sizeof(ResultRec), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const ResultRec* hr = (const ResultRec*)(pin_dst + res_at);
+    if (hr->status != ST_OK) { set_last_error("device compress status %u", hr->status); return make_err((int)hr->status); }
+    *size = hr->size;
+    (void)pin_res;
     return 0;
 }
 

@@ -117,6 +117,12 @@ struct lz4f_mi355x_engine {
     size_t slab_compress(const uint8_t* src, size_t n, const uint8_t* hist, size_t hist_len, uint32_t block_size, bool linked, bool block_checksum,
                          bool src_pinned, size_t* size);
     size_t slab_fetch(uint8_t* dst, size_t size, size_t d_off, bool dst_pinned);
+    // One block (or a short run of them) out of page-locked host memory and back into it, no copy calls: the kernels read the input
+    // (hist_len bytes of history, then n bytes) and write the block(s) and the result record through the link themselves.  What the
+    // LZ4F_* streaming functions do per completed block (frame_host.cpp): upload, download and one of the two synchronisations of the
+    // staged path are gone.  Both buffers from lz4f::PinBuf (hipHostMalloc).
+    size_t compress_block_pinned(const uint8_t* pin_src, size_t hist_len, size_t n, uint32_t block_size, bool linked, bool block_checksum,
+                                 uint8_t* pin_dst, size_t dst_cap, void* pin_res, size_t* size);
     size_t slab_decode(const uint8_t* frame_part, size_t part_len, const std::vector<lz4f_mi355x_block>& entries, const lz4f::ParsedHeader& ph,
                        const uint8_t* hist, size_t hist_len, bool src_pinned, size_t* got);
     // Decode one compressed block payload (host; followed by its 4-byte checksum when bck) with `hist_len`

@@ -159,33 +159,74 @@ struct LZ4F_cctx_s {
     unsigned version;
     int stage;                       // 0 = idle, 1 = header written
     size_t block_size;
-    std::vector<uint8_t> tmp;        // staged input, always < block_size between calls
-    std::vector<uint8_t> hist;       // last <= 64 KiB of input already encoded (linked mode)
-    std::vector<uint8_t> work;
+    // Page-locked staging the kernels read and write directly (engine: compress_block_pinned): pin_in = [64 KiB: the last <= 64 KiB of
+    // input already encoded (linked mode), right-aligned][block_size: the input staged for the next block, always < block_size between
+    // calls]; pin_out = the encoded block(s) of one call, then the result record.
+    PinBuf pin_in, pin_out;
+    std::vector<uint8_t> pageable;   // the same staging in ordinary memory where page-locked memory cannot be had (no usable device: block-level calls then fail loudly, staging does not)
+    uint8_t* base = nullptr;
+    size_t tmp_size, hist_len;
     uint64_t total_in;
     Xxh32State xxh;
+    bool pinned() const { return base && base == (uint8_t*)pin_in.p; }
+    uint8_t* stage_at() { return base + 65536; }
+    const uint8_t* hist_at() const { return base + 65536 - hist_len; }
+    bool ensure_staging()
+    {
+        if (base) return true;
+        const size_t need = 65536 + block_size + 64;
+        if (!pin_in.ensure(need)) { base = (uint8_t*)pin_in.p; return true; }
+        try { pageable.assign(need, 0); } catch (...) { return false; }
+        base = pageable.data();
+        return true;
+    }
+    ~LZ4F_cctx_s() { pin_in.release(); pin_out.release(); }
 };
 
 static void push_history(LZ4F_cctx_s* c, const uint8_t* p, size_t n)
 {
     if (c->prefs.frameInfo.blockMode != LZ4F_blockLinked) return;
-    if (n >= 65536) { c->hist.assign(p + n - 65536, p + n); return; }
-    c->hist.insert(c->hist.end(), p, p + n);
-    if (c->hist.size() > 65536) c->hist.erase(c->hist.begin(), c->hist.begin() + (c->hist.size() - 65536));
+    uint8_t* base = c->base;
+    if (n >= 65536) { memmove(base, p + n - 65536, 65536); c->hist_len = 65536; return; }
+    const size_t new_len = std::min<size_t>(65536, c->hist_len + n), keep_old = new_len - n;
+    memmove(base + 65536 - new_len, base + 65536 - keep_old, keep_old);      // (the old bytes that stay, moved down by n)
+    memmove(base + 65536 - n, p, n);
+    c->hist_len = new_len;
 }
 
-// encode `n` bytes (whole blocks, the last may be short) -> appended to dst; returns bytes written or error
+// encode `n` bytes (whole blocks, the last may be short) that lie anywhere in host memory -> dst; returns bytes written or error
 static size_t encode_blocks(LZ4F_cctx_s* c, uint8_t* dst, size_t cap, const uint8_t* src, size_t n)
 {
     EngineLease eng;
     size_t r = eng.get();
     if (is_err(r)) return r;
     size_t written = 0;
-    r = eng->compress_blocks_host(src, n, c->hist.data(), c->hist.size(), (uint32_t)c->block_size,
+    r = eng->compress_blocks_host(src, n, c->hist_at(), c->hist_len, (uint32_t)c->block_size,
                                   c->prefs.frameInfo.blockMode == LZ4F_blockLinked, c->prefs.frameInfo.blockChecksumFlag != 0, dst, cap, &written);
     if (is_err(r)) return r;
     push_history(c, src, n);
     return written;
+}
+
+// encode the `n` <= block_size bytes staged in pin_in (one block) -> dst.  The kernels read the staging buffer and write the block into
+// pin_out through the link themselves: no copy calls, one synchronisation.
+static size_t encode_staged(LZ4F_cctx_s* c, uint8_t* dst, size_t cap, size_t n)
+{
+    if (!c->pinned()) return encode_blocks(c, dst, cap, c->stage_at(), n);      // (staged copies; without a device this is where the call fails, loudly)
+    EngineLease eng;
+    size_t r = eng.get();
+    if (is_err(r)) return r;
+    const size_t out_cap = n + 256;
+    if (c->pin_out.ensure(out_cap + 256)) return make_err(LZ4F_ERROR_allocation_failed);
+    uint8_t* out = (uint8_t*)c->pin_out.p;
+    size_t size = 0;
+    r = eng->compress_block_pinned(c->hist_at(), c->hist_len, n, (uint32_t)c->block_size, c->prefs.frameInfo.blockMode == LZ4F_blockLinked,
+                                   c->prefs.frameInfo.blockChecksumFlag != 0, out, out_cap + 192, nullptr, &size);
+    if (is_err(r)) return r;
+    if (size > cap) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
+    memcpy(dst, out, size);
+    push_history(c, c->stage_at(), n);
+    return size;
 }
 
 extern "C" {
@@ -200,7 +241,7 @@ LZ4F_errorCode_t LZ4F_createCompressionContext(LZ4F_cctx** cctxPtr, unsigned ver
     LZ4F_cctx_s* c = new (std::nothrow) LZ4F_cctx_s();
     if (!c) return make_err(LZ4F_ERROR_allocation_failed);
     memset(&c->prefs, 0, sizeof(c->prefs));
-    c->version = version; c->stage = 0; c->block_size = 0; c->total_in = 0;
+    c->version = version; c->stage = 0; c->block_size = 0; c->total_in = 0; c->tmp_size = 0; c->hist_len = 0;
     *cctxPtr = c;
     return 0;
 }
@@ -226,7 +267,8 @@ size_t LZ4F_compressBegin(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, con
     if (c->prefs.frameInfo.blockSizeID == 0) c->prefs.frameInfo.blockSizeID = LZ4F_max64KB;
     c->block_size = block_size_of(c->prefs.frameInfo.blockSizeID);
     if (!c->block_size) return make_err(LZ4F_ERROR_maxBlockSize_invalid);
-    c->tmp.clear(); c->hist.clear(); c->total_in = 0;
+    c->tmp_size = 0; c->hist_len = 0; c->total_in = 0;
+    c->base = nullptr;                                                    // (staging is made by the first LZ4F_compressUpdate: the block size may have changed)
     c->xxh.reset(0);
     const size_t h = write_frame_header((uint8_t*)dstBuffer, c->prefs);
     c->stage = 1;
@@ -237,28 +279,32 @@ size_t LZ4F_compressUpdate(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, co
                            const LZ4F_compressOptions_t* /*cOptPtr: stableSrc is irrelevant, input is staged to the GPU anyway*/)
 {
     if (!c || c->stage != 1) return make_err(LZ4F_ERROR_GENERIC);
-    if (dstCapacity < compress_bound_internal(srcSize, &c->prefs, c->tmp.size())) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
+    if (dstCapacity < compress_bound_internal(srcSize, &c->prefs, c->tmp_size)) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
+    if (!c->ensure_staging()) return make_err(LZ4F_ERROR_allocation_failed);
     const uint8_t* src = (const uint8_t*)srcBuffer;
     uint8_t* dst = (uint8_t*)dstBuffer;
     const size_t B = c->block_size;
     size_t written = 0, pos = 0;
-    const size_t avail = c->tmp.size() + srcSize;
+    const size_t avail = c->tmp_size + srcSize;
     size_t whole = (avail / B) * B;                           // bytes that form complete blocks
     if (c->prefs.autoFlush) whole = avail;                    // ... or everything
     if (whole) {
-        const uint8_t* in; size_t n = whole;
-        if (!c->tmp.empty()) {                               // complete the staged block first: needs one contiguous run
-            c->work.assign(c->tmp.begin(), c->tmp.end());
-            pos = whole - c->tmp.size();
-            c->work.insert(c->work.end(), src, src + pos);
-            c->tmp.clear();
-            in = c->work.data();
-        } else { in = src; pos = whole; }
-        const size_t r = encode_blocks(c, dst, dstCapacity, in, n);
-        if (is_err(r)) return r;
-        written += r;
+        if (c->tmp_size) {                                   // complete the staged block first (the reference's pattern: every call that emits, emits this one block)
+            const size_t take = std::min(std::min(B - c->tmp_size, srcSize), whole - c->tmp_size);
+            memcpy(c->stage_at() + c->tmp_size, src, take);
+            const size_t n1 = c->tmp_size + take;
+            c->tmp_size = 0; pos = take;
+            const size_t r = encode_staged(c, dst, dstCapacity, n1);
+            if (is_err(r)) return r;
+            written += r; whole -= n1;
+        }
+        if (whole) {                                         // further whole blocks straight from the caller's buffer
+            const size_t r = encode_blocks(c, dst + written, dstCapacity - written, src + pos, whole);
+            if (is_err(r)) return r;
+            written += r; pos += whole;
+        }
     }
-    if (pos < srcSize) c->tmp.insert(c->tmp.end(), src + pos, src + srcSize);      // necessarily < B
+    if (pos < srcSize) { memcpy(c->stage_at() + c->tmp_size, src + pos, srcSize - pos); c->tmp_size += srcSize - pos; }      // necessarily < B
     if (c->prefs.frameInfo.contentChecksumFlag == LZ4F_contentChecksumEnabled) c->xxh.update(srcBuffer, srcSize);
     c->total_in += srcSize;
     return written;
@@ -267,12 +313,12 @@ size_t LZ4F_compressUpdate(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, co
 size_t LZ4F_flush(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t*)
 {
     if (!c) return make_err(LZ4F_ERROR_GENERIC);
-    if (c->tmp.empty()) return 0;
+    if (c->tmp_size == 0) return 0;
     if (c->stage != 1) return make_err(LZ4F_ERROR_GENERIC);
-    if (dstCapacity < c->tmp.size() + 8) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
-    c->work.assign(c->tmp.begin(), c->tmp.end());
-    c->tmp.clear();
-    return encode_blocks(c, (uint8_t*)dstBuffer, dstCapacity, c->work.data(), c->work.size());
+    if (dstCapacity < c->tmp_size + 8) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
+    const size_t n = c->tmp_size;
+    c->tmp_size = 0;
+    return encode_staged(c, (uint8_t*)dstBuffer, dstCapacity, n);
 }
 
 size_t LZ4F_compressEnd(LZ4F_cctx* c, void* dstBuffer, size_t dstCapacity, const LZ4F_compressOptions_t* o)
