@@ -133,6 +133,12 @@ static_assert(64 * E1_WAVES >= E1_NSLICE, "a thread per slice when the lists are
 #ifndef E1_DENSE_PASS
 #define E1_DENSE_PASS 1
 #endif
+#ifndef E1_V2
+#define E1_V2 1
+#endif
+#ifndef E1_V3
+#define E1_V3 1
+#endif
 constexpr uint32_t E1_GRAB_SPARSE = E1_GRAB, E1_GRAB_DENSE = E1_GRAB_D, E1_PROBE_SLICES = 16, E1_DENSE_HITS = 24;
 
 // 4 / 8 bytes at any byte position of the ring.  (A byte-unaligned ds_read_b32 / _b64 is legal on gfx950 but keeps the LDS busy
@@ -494,24 +500,65 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                     const uint32_t ipB = ip + WAVE * step, stepB = step + 1;
                     const uint32_t pA = ip + lane * step, pB = ipB + lane * stepB;
                     const bool actA = pA <= last_start, actB = two && pB <= last_start;
+#if E1_V3
+                    // (both steps' words asked for before either is looked at, then both steps' table entries: two LDS round trips on the
+                    // path of a step that finds nothing instead of three - the compiler, left alone, asks for B's words behind A's wait)
+                    const uint32_t iA = pA & E1_RMASK, iB = pB & E1_RMASK;
+                    const e1_w2 wA = *(const e1_w2*)(sh.ring + (iA & ~3u)), wB = *(const e1_w2*)(sh.ring + (iB & ~3u));
+                    __builtin_amdgcn_sched_barrier(0);
+                    const uint32_t vA = __builtin_amdgcn_alignbyte(wA.b, wA.a, iA & 3u), vB = __builtin_amdgcn_alignbyte(wB.b, wB.a, iB & 3u);
+                    const uint32_t hvA = e1_mix(vA), hA = e1_slot(hvA), tgA = e1_tag(hvA);
+                    const uint32_t hvB = e1_mix(vB), hB = e1_slot(hvB), tgB = e1_tag(hvB);
+                    const uint32_t eA = sh.table[hA], etA = sh.tags[hA], eB = sh.table[hB], etB = sh.tags[hB];
+                    __builtin_amdgcn_sched_barrier(0);
+#else
                     const uint32_t vA = e1_ld32(sh.ring, pA), vB = e1_ld32(sh.ring, pB);      // (idle lanes read on in the ring: harmless)
                     const uint32_t hvA = e1_mix(vA), hA = e1_slot(hvA), tgA = e1_tag(hvA);
                     const uint32_t hvB = e1_mix(vB), hB = e1_slot(hvB), tgB = e1_tag(hvB);
                     const uint32_t eA = sh.table[hA], etA = sh.tags[hA], eB = sh.table[hB], etB = sh.tags[hB];
+#endif
                     const uint32_t distA = (pA - eA) & 0xFFFFu, distB = (pB - eB) & 0xFFFFu;
                     // 21 hash bits agree: worth a look at the bytes (in incompressible input one step in five gets that far).
                     // Written so that each question is ONE vector compare whose result IS the ballot: tag difference, distance range and
                     // "is this lane probing at all" folded into x < limit.  (As a chain of && hipcc makes an exec-mask block per term -
                     // save, branch, restore on the scalar unit, which the 16 waves of the workgroup share and this loop runs out of.)
                     const uint32_t roomA = pA - low, roomB = pB - low;                                   // (a distance is < 2^16 anyway: the cap keeps the marker bits above any limit)
-                    const uint32_t limA = actA ? (roomA < 65536u ? roomA : 65536u) : 0u, limB = actB ? (roomB < 65536u ? roomB : 65536u) : 0u;
+#if E1_V3
+                    // (the limit is capped at 65535, LZ4's largest offset: a distance of 0 - an empty slot, or the position itself 64 KiB on - reads
+                    // as 0xFFFF here and fails the compare by itself, no marker bit of its own)
+                    const uint32_t xA = (uint32_t)(uint16_t)((uint16_t)distA - (uint16_t)1u) | ((etA ^ tgA) << 20);
+                    const uint32_t xB = (uint32_t)(uint16_t)((uint16_t)distB - (uint16_t)1u) | ((etB ^ tgB) << 20);
+#else
                     const uint32_t xA = ((distA - 1u) & 0xFFFFu) | ((etA ^ tgA) << 20) | (distA == 0u ? 1u << 19 : 0u);
                     const uint32_t xB = ((distB - 1u) & 0xFFFFu) | ((etB ^ tgB) << 20) | (distB == 0u ? 1u << 19 : 0u);
+#endif
                     // The table is shared with waves further ahead, and a run of one byte (or of a short period) is a single hot slot that
                     // always holds a position of whoever is furthest ahead.  Such runs are found without it: the lane below probes the
                     // position `step` bytes back, and if its four bytes are mine, that is a match.
-                    const uint32_t nbA = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vA, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
-                    const uint32_t nbB = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vB, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+                    const uint32_t nbA = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vA, 0x111 /* row_shr:1 */, 0xf, 0xf, E1_V3 ? true : false);
+                    const uint32_t nbB = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)vB, 0x111 /* row_shr:1 */, 0xf, 0xf, E1_V3 ? true : false);
+#if E1_V2
+                    // (round 3: a run candidate is a candidate like the table's - distance `step`, checked against the bytes like them - instead of
+                    // a ballot of its own, and "is this lane probing at all" is a scalar mask on the ballots instead of a select per lane:
+                    // ~14 instructions off a step of ~125, none of them a branch)
+                    const uint64_t actmA = __ballot(pA <= last_start), actmB = __ballot(pB <= last_start) & (two ? ~0ull : 0ull);
+                    constexpr uint32_t LIMCAP = E1_V3 ? 65535u : 65536u;
+                    const uint32_t limA = roomA < LIMCAP ? roomA : LIMCAP, limB = roomB < LIMCAP ? roomB : LIMCAP;
+                    const bool rleA = nbA == vA, rleB = nbB == vB;              // (a row's first lane sees 0 for its neighbour: a false alarm there does not survive the byte compare)
+                    const uint32_t dA = rleA ? step : distA, dB = rleB ? stepB : distB;
+                    const uint32_t yA = rleA ? step - 1u : xA, yB = rleB ? stepB - 1u : xB;
+                    uint64_t m = __ballot(yA < limA) & actmA;
+                    if (m) m &= __ballot(e1_ld32(sh.ring, pA - dA) == vA);                       // (every lane looks: harmless, the ring is a power of two)
+                    bool inB = false;
+                    if (!m) {
+                        // (lanes that have nothing to insert store to a word of their own: a select on the address instead of an exec-mask block)
+                        *(actA ? &sh.table[hA] : (uint16_t*)&sh.idle[lane]) = (uint16_t)pA; *(actA ? &sh.tags[hA] : (uint8_t*)&sh.idle[lane]) = (uint8_t)tgA;
+                        m = __ballot(yB < limB) & actmB;
+                        if (m) m &= __ballot(e1_ld32(sh.ring, pB - dB) == vB);
+                        inB = true;
+                    }
+#else
+                    const uint32_t limA = actA ? (roomA < 65536u ? roomA : 65536u) : 0u, limB = actB ? (roomB < 65536u ? roomB : 65536u) : 0u;
                     const uint32_t row0 = (lane & 15u) == 0u ? 1u : 0u;
                     uint64_t m = __ballot(xA < limA);
                     if (m) m &= __ballot(e1_ld32(sh.ring, pA - distA) == vA);                    // (every lane looks: harmless, the ring is a power of two)
@@ -527,6 +574,8 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                         m |= mr;
                         inB = true;
                     }
+                    const uint32_t dA = ((mr >> lane) & 1ull) ? step : distA, dB = ((mr >> lane) & 1ull) ? stepB : distB;
+#endif
                     // the greedy parse indexes the positions up to the match it takes, not the ones it jumps over: those come up
                     // again in the next step and would find themselves in the table instead of their candidates
                     const uint32_t L = m ? (uint32_t)__builtin_ctzll(m) : WAVE;
@@ -545,7 +594,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                     // chosen lanes write their records themselves.  A match of 20 bytes or more ends the pass and is taken by the code
                     // below, which extends it as far as it goes.
                     if (E1_DENSE_PASS && !inB && mode == 2 && step == 1) {
-                        const uint32_t di = ((mr >> lane) & 1ull) ? 1u : distA;
+                        const uint32_t di = dA;                                               // (step == 1 here: a run candidate's distance is 1)
                         const uint64_t x0 = e1_ld64(sh.ring, pA + 4) ^ e1_ld64(sh.ring, pA + 4 - di);
                         const uint64_t x1 = e1_ld64(sh.ring, pA + 12) ^ e1_ld64(sh.ring, pA + 12 - di);
                         const uint32_t xb = e1_ld32(sh.ring, pA - 4) ^ e1_ld32(sh.ring, pA - 4 - di);
@@ -592,7 +641,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                         }
                     }
                     E1DBG(if (blockIdx.x == 0 && lane == 0) { atomicAdd((unsigned long long*)&scratch[E1_DBG_AT + 4 + (inB ? 0 : mode != 2 ? 1 : step != 1 ? 2 : 3)], 1ull); })
-                    const uint32_t dsel = ((mr >> lane) & 1ull) ? (inB ? stepB : step) : (inB ? distB : distA);
+                    const uint32_t dsel = inB ? dB : dA;
                     uint32_t mp = (uint32_t)__builtin_amdgcn_readlane(inB ? pB : pA, L);
                     const uint32_t d = (uint32_t)__builtin_amdgcn_readlane(dsel, L);
                     // backwards: up to the last match end (or where this slice began) and the lowest position a match may read
