@@ -139,6 +139,9 @@ static_assert(64 * E1_WAVES >= E1_NSLICE, "a thread per slice when the lists are
 #ifndef E1_V3
 #define E1_V3 1
 #endif
+#ifndef E1_V4
+#define E1_V4 1
+#endif
 constexpr uint32_t E1_GRAB_SPARSE = E1_GRAB, E1_GRAB_DENSE = E1_GRAB_D, E1_PROBE_SLICES = 16, E1_DENSE_HITS = 24;
 
 // 4 / 8 bytes at any byte position of the ring.  (A byte-unaligned ds_read_b32 / _b64 is legal on gfx950 but keeps the LDS busy
@@ -157,6 +160,22 @@ __device__ __forceinline__ uint64_t e1_ld64(const uint8_t* ring, uint32_t pos)
     const uint32_t i = pos & E1_RMASK;
     const e1_w3 w = *(const e1_w3*)(ring + (i & ~3u));
     return (uint64_t)__builtin_amdgcn_alignbyte(w.b, w.a, i & 3u) | ((uint64_t)__builtin_amdgcn_alignbyte(w.c, w.b, i & 3u) << 32);
+}
+// five dwords from the dword at or below pos: 16 bytes at any byte position, picked with v_alignbyte by the caller
+struct __attribute__((aligned(4))) e1_w5 { uint32_t a, b, c, d, e; };
+__device__ __forceinline__ e1_w5 e1_ld5(const uint8_t* ring, uint32_t pos)
+{
+    return *(const e1_w5*)(ring + ((pos & E1_RMASK) & ~3u));
+}
+// how many of the 16 bytes at two positions (given as five dwords each + the positions' byte phases) agree, from the first on
+__device__ __forceinline__ uint32_t e1_same16(const e1_w5& s1, const e1_w5& s2, uint32_t k1, uint32_t k2)
+{
+    const uint32_t x0 = __builtin_amdgcn_alignbyte(s1.b, s1.a, k1) ^ __builtin_amdgcn_alignbyte(s2.b, s2.a, k2);
+    const uint32_t x1 = __builtin_amdgcn_alignbyte(s1.c, s1.b, k1) ^ __builtin_amdgcn_alignbyte(s2.c, s2.b, k2);
+    const uint32_t x2 = __builtin_amdgcn_alignbyte(s1.d, s1.c, k1) ^ __builtin_amdgcn_alignbyte(s2.d, s2.c, k2);
+    const uint32_t x3 = __builtin_amdgcn_alignbyte(s1.e, s1.d, k1) ^ __builtin_amdgcn_alignbyte(s2.e, s2.d, k2);
+    const uint64_t lo = (uint64_t)x0 | ((uint64_t)x1 << 32), hi = (uint64_t)x2 | ((uint64_t)x3 << 32);
+    return lo ? (uint32_t)(__builtin_ctzll(lo) >> 3) : hi ? 8u + (uint32_t)(__builtin_ctzll(hi) >> 3) : 16u;
 }
 __device__ __forceinline__ uint32_t e1_mix(uint32_t v) { return v * 2654435761u; }
 __device__ __forceinline__ uint32_t e1_slot(uint32_t hv) { return hv >> (32 - E1_HASH_LOG); }
@@ -648,6 +667,47 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                     uint32_t room = mp - (anchor > floor_b ? anchor : floor_b); if (mp - d - low < room) room = mp - d - low;
                     uint32_t nb = 0;
                     E1DBG(uint32_t itb = 0;)
+#if E1_V4
+                    // (round 3: no exec-mask blocks in the two loops - every lane reads, which is harmless in a ring, and the limits are applied to
+                    // the counts; the first backward round and the first forward round are asked for together; forwards 16 bytes per lane, so
+                    // that a 512-byte match ends in the round it starts in)
+                    uint32_t fw = 0;
+                    {
+                        const uint32_t kb = lane + 1;
+                        const uint32_t b1 = sh.ring[(mp - kb) & E1_RMASK], b2 = sh.ring[(mp - d - kb) & E1_RMASK];
+                        const uint32_t a0 = mp + lane * 16;
+                        const e1_w5 s1 = e1_ld5(sh.ring, a0), s2 = e1_ld5(sh.ring, a0 - d);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const uint64_t ne = __ballot(b1 != b2 || kb > room);
+                        nb = ne ? (uint32_t)__builtin_ctzll(ne) : WAVE;
+                        uint32_t g0 = e1_same16(s1, s2, a0 & 3u, (a0 - d) & 3u);
+                        const int32_t r = (int32_t)(end_lim - a0); g0 = r <= 0 ? 0u : (g0 > (uint32_t)r ? (uint32_t)r : g0);
+                        const uint64_t stop = __ballot(g0 < 16);
+                        if (stop) { const uint32_t f = (uint32_t)__builtin_ctzll(stop); fw = f * 16 + (uint32_t)__builtin_amdgcn_readlane(g0, f); }
+                        else fw = WAVE * 16 | 0x80000000u;                       // (goes on)
+                    }
+                    for (bool more = nb == WAVE; more;) {                        // (rare: more than 64 bytes backwards)
+                        E1DBG(if (++itb > 100000) { if (lane == 0) { atomicAdd((unsigned long long*)&scratch[E1_DBG_AT + 2], 1ull); scratch[E1_DBG_AT + 10] = ((uint64_t)room << 32) | nb; } break; })
+                        const uint32_t kb = nb + lane + 1;
+                        const uint32_t b1 = sh.ring[(mp - kb) & E1_RMASK], b2 = sh.ring[(mp - d - kb) & E1_RMASK];
+                        const uint64_t ne = __ballot(b1 != b2 || kb > room);
+                        const uint32_t n1 = ne ? (uint32_t)__builtin_ctzll(ne) : WAVE;
+                        nb += n1;
+                        more = n1 == WAVE;
+                    }
+                    E1DBG(uint32_t itf = 0;)
+                    while (fw >> 31) {
+                        fw &= 0x7FFFFFFFu;
+                        E1DBG(if (++itf > 100000) { if (lane == 0) { atomicAdd((unsigned long long*)&scratch[E1_DBG_AT + 3], 1ull); scratch[E1_DBG_AT + 11] = ((uint64_t)mp << 32) | fw; scratch[E1_DBG_AT + 12] = ((uint64_t)end_lim << 32) | d; } break; })
+                        const uint32_t a0 = mp + fw + lane * 16;
+                        const e1_w5 s1 = e1_ld5(sh.ring, a0), s2 = e1_ld5(sh.ring, a0 - d);
+                        uint32_t g0 = e1_same16(s1, s2, a0 & 3u, (a0 - d) & 3u);
+                        const int32_t r = (int32_t)(end_lim - a0); g0 = r <= 0 ? 0u : (g0 > (uint32_t)r ? (uint32_t)r : g0);
+                        const uint64_t stop = __ballot(g0 < 16);
+                        if (stop) { const uint32_t f = (uint32_t)__builtin_ctzll(stop); fw += f * 16 + (uint32_t)__builtin_amdgcn_readlane(g0, f); }
+                        else fw = (fw + WAVE * 16) | 0x80000000u;
+                    }
+#else
                     for (;;) {
                         E1DBG(if (++itb > 100000) { if (lane == 0) { atomicAdd((unsigned long long*)&scratch[E1_DBG_AT + 2], 1ull); scratch[E1_DBG_AT + 10] = ((uint64_t)room << 32) | nb; } break; })
                         const uint32_t kb = nb + lane + 1;
@@ -673,6 +733,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                         if (stop) { const uint32_t f = (uint32_t)__builtin_ctzll(stop); fw += f * 8 + (uint32_t)__builtin_amdgcn_readlane(g0, f); break; }
                         fw += WAVE * 8;
                     }
+#endif
                     mp -= nb;
                     const uint32_t mlen = nb + fw;
                     myrec[nrec] = pack_rec(mp - anchor, mlen, d);              // (every lane stores the same 8 bytes)
