@@ -43,7 +43,7 @@ GIB = float(1 << 30)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 HBM_COPY_GBS = 6290.0
 PCIE_GBS = 63.0                # MI355X_MICROARCH.md: PCIe Gen5 x16, 63 GB/s spec (53-54 GiB/s measured each way, tools/probe/pcie_rates.py)
-PMC_PROFILE = "profiles/round2b_pmc_traffic.json"
+PMC_PROFILE = "profiles/round3_pmc_traffic.json"
 
 
 def pmc_traffic(kernel: str, n_bytes: int, block_size: int):
