@@ -32,6 +32,9 @@ constexpr uint32_t FZ_OVER = 576;                // >= the parser's 520-byte reg
 #ifndef FZ_FED_ROUNDS
 #define FZ_FED_ROUNDS 1                          // gather rounds per register set in the fed copiers (two sets in flight)
 #endif
+#ifndef FZ_STORE_SC1          // how the fed copiers store output: 0 non-temporal (keeps the line in L2), 1 sc1, 2 sc0 sc1 (write-through, dropped from L2), 3 plain
+#define FZ_STORE_SC1 0
+#endif
 #ifndef FZ_FED_OCC
 #define FZ_FED_OCC 8
 #endif
@@ -423,7 +426,15 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
                 typedef u32x4 u32x4_ua __attribute__((aligned(1)));
                 auto st = [&](const Piece& pc, uint32_t dof, bool act) {
                     if (!act) return;
+#if FZ_STORE_SC1 == 1
+                    if (FED) { const u32x4 v = u32x4{pc.a, pc.b, pc.c, pc.d}; uint8_t* q = out + dof; asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(q), "v"(v) : "memory"); }
+#elif FZ_STORE_SC1 == 2
+                    if (FED) { const u32x4 v = u32x4{pc.a, pc.b, pc.c, pc.d}; uint8_t* q = out + dof; asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" :: "v"(q), "v"(v) : "memory"); }
+#elif FZ_STORE_SC1 == 3
+                    if (FED) *(v4u_ua*)(out + dof) = v4u_ua{pc.a, pc.b, pc.c, pc.d};
+#else
                     if (FED) __builtin_nontemporal_store(u32x4{pc.a, pc.b, pc.c, pc.d}, (u32x4_ua*)(out + dof));
+#endif
                     else *(v4u_ua*)(out + dof) = v4u_ua{pc.a, pc.b, pc.c, pc.d};
                 };
                 // ping-pong of G rounds each: loads are in flight while the previous set is stored
