@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <exception>
 #include <functional>
 #include <thread>
 #include <new>
@@ -734,9 +735,13 @@ size_t lz4f_mi355x_compressFrame(void* dst, size_t dstCapacity, const void* src,
     std::thread hasher;
     const bool want_cck = p.frameInfo.contentChecksumFlag == LZ4F_contentChecksumEnabled;
     if (want_cck) hasher = std::thread([&] { cck = xxh32_host(src, srcSize); });
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } join_hasher{hasher};      // (also when the pipeline throws: bad_alloc, thread creation)
     size_t written = 0;
-    size_t r = pipe_compress_blocks((const uint8_t*)src, srcSize, (uint32_t)bs, p.frameInfo.blockMode == LZ4F_blockLinked, p.frameInfo.blockChecksumFlag != 0,
-                                    d + used, dstCapacity - used, &written);
+    size_t r;
+    try {
+        r = pipe_compress_blocks((const uint8_t*)src, srcSize, (uint32_t)bs, p.frameInfo.blockMode == LZ4F_blockLinked, p.frameInfo.blockChecksumFlag != 0,
+                                 d + used, dstCapacity - used, &written);
+    } catch (const std::exception& e) { set_last_error("compressFrame: %s", e.what()); r = make_err(LZ4F_ERROR_allocation_failed); }
     if (want_cck) hasher.join();
     if (is_err(r)) return r;
     used += written;
@@ -771,13 +776,16 @@ static size_t decompress_frame_common(void* dst, size_t dstCapacity, const void*
 
 size_t lz4f_mi355x_decompressFrame(void* dst, size_t dstCapacity, const void* src, size_t srcSize, size_t* srcConsumed)
 {
-    return decompress_frame_common(dst, dstCapacity, src, srcSize, srcConsumed, nullptr);
+    try { return decompress_frame_common(dst, dstCapacity, src, srcSize, srcConsumed, nullptr); }
+    catch (const std::exception& e) { set_last_error("decompressFrame: %s", e.what()); return make_err(LZ4F_ERROR_allocation_failed); }      // (nothing may unwind through the C boundary)
 }
 
 size_t lz4f_mi355x_decompressFrameTo(lz4f_mi355x_yield_fn yield, void* user, const void* src, size_t srcSize, size_t* srcConsumed)
 {
     if (!yield) return make_err(LZ4F_ERROR_GENERIC);
     const std::function<void(const uint8_t*, size_t)> sink = [&](const uint8_t* p, size_t n) { yield(user, p, n); };
+    // (a C++ caller's yield may throw - conduit.cpp's does: the pipeline joins its workers first, then the exception goes back to that caller;
+    // a C or Haskell caller's callback cannot throw)
     return decompress_frame_common(nullptr, 0, src, srcSize, srcConsumed, &sink);
 }
 

@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <condition_variable>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -219,6 +220,7 @@ size_t pipe_decompress_frame(const uint8_t* s, size_t n, const ParsedHeader& ph,
         };
         if (sink) {
             // every slot on a thread of its own; this thread hands the slabs to the caller's sink, in order
+            std::exception_ptr sink_failed;
             std::vector<std::thread> th;
             for (size_t sl = 0; sl < nslot; sl++) th.emplace_back(work, sl);
             for (size_t k = 0; k < nslab; k++) {
@@ -227,12 +229,16 @@ size_t pipe_decompress_frame(const uint8_t* s, size_t n, const ParsedHeader& ph,
                 if (turns.err) break;
                 const uint8_t* ptr = ready_ptr; const size_t len = ready_len;
                 g.unlock();
-                (*sink)(ptr, len);
+                // (the sink is the caller's code - a conduit's yield - and may throw: the workers are joinable threads, so the failure is
+                // recorded, they are let go and joined, and only then does the exception travel on)
+                try { (*sink)(ptr, len); }
+                catch (...) { sink_failed = std::current_exception(); turns.fail(make_err(LZ4F_ERROR_GENERIC)); g.lock(); ready = false; turns.cv.notify_all(); break; }
                 g.lock();
                 ready = false;
                 turns.cv.notify_all();
             }
             for (auto& t : th) t.join();
+            if (sink_failed) std::rethrow_exception(sink_failed);
         } else if (nslot == 1) work(0);
         else {
             std::vector<std::thread> th;
