@@ -126,7 +126,7 @@ def main():
         if args.gpus > 1:
             import socket
             import torch                              # (counting devices does not initialise the GPU; the ranks are children of this process)
-            if torch.cuda.device_count() < args.gpus:
+            if torch.cuda.device_count() < args.gpus and not os.environ.get("LZ4F_BENCH_SHARE_GPU"):
                 sys.exit("bench.py: --gpus %d but %d GPU(s) are visible: one process per GPU, no oversubscription" % (args.gpus, torch.cuda.device_count()))
             with socket.socket() as s_:
                 s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]
@@ -142,7 +142,11 @@ def main():
     import torch.distributed as dist
 
     have = torch.cuda.device_count()              # (counting does not initialise the GPU)
-    if have < args.gpus:
+    # LZ4F_BENCH_SHARE_GPU=1 (a test switch, tests/test_distributed_cpu.py): the ranks share the visible GPU(s), rank r on device r mod visible, and
+    # meet over gloo (RCCL refuses two ranks on one device) - the launch, the rendezvous, the barrier and the max-over-ranks time run as they do
+    # on N GPUs; the number it prints is not a measurement of anything
+    share = bool(os.environ.get("LZ4F_BENCH_SHARE_GPU")) and have >= 1
+    if have < args.gpus and not share:
         sys.exit("bench.py: --gpus %d but %d GPU(s) are visible: one process per GPU, no oversubscription" % (args.gpus, have))
 
     from lz4_frame_conduit_amd import _ffi, conduit, datagen, shard
@@ -151,11 +155,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if share: local_rank = local_rank % have
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share: dist.init_process_group("gloo")
+        else: dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
@@ -194,7 +200,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    dt = shard.max_over_ranks(dt, dev)
+    dt = shard.max_over_ranks(dt, "cpu" if share else dev)
     kt = {}
     if rank == 0:                                             # per-kernel HIP-event times of the last timed step
         kt = dict(eng.get_timing())

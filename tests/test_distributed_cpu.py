@@ -157,3 +157,23 @@ def test_bench_gpus_flag_is_honoured():
     env["WORLD_SIZE"] = "3"
     r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr, (r.returncode, r.stderr[-400:])
+
+
+@pytest.mark.gpu
+def test_bench_n_rank_path_on_a_shared_gpu():
+    """`bench.py --gpus 2` end to end on the one-GPU box: the parent starts two ranks (torch.distributed.run, 127.0.0.1), each builds its own
+    stream (seed 1234 + rank), they meet at the barriers, rank 0 takes the maximum of the times and prints ONE JSON line with n_gpus = 2 and the
+    aggregate over both ranks.  LZ4F_BENCH_SHARE_GPU=1 is what makes that possible here: both ranks on the visible GPU, gloo for the rendezvous
+    (RCCL refuses two ranks on one device); on an N-GPU node the same code runs one rank per GPU over RCCL."""
+    import json, subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["LZ4F_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--bytes", str(256 << 20), "--headline-only", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stdout[-300:], r.stderr[-1200:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-500:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["roundtrip_verified"] is True and d["scaling"] == "weak"
+    assert d["config"]["rccl_ranks"] == 2 and d["config"]["bytes_per_gpu"] == 256 << 20 and d["value"] > 0
+    assert abs(d["value"] - 2 * (256 << 20) * 2 / (d["ms_per_step"] * 2 * 1e-3) / 2**30) < 0.02 * d["value"]      # the aggregate of both ranks over the slowest rank's time
