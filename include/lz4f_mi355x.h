@@ -170,6 +170,18 @@ LZ4F_MI355X_API size_t lz4f_mi355x_compressFrameBound(size_t srcSize, const LZ4F
  * match finder's choice of matches, which is not deterministic). */
 LZ4F_MI355X_API size_t lz4f_mi355x_compressFrame(void* dst, size_t dstCapacity, const void* src, size_t srcSize,
                                                  const LZ4F_preferences_t* prefs);
+/* BLOCK LIST of a finished frame held in host memory - a frame of this library's host paths (compressFrame, the LZ4F_* streaming
+ * calls, the conduits) or of any other LZ4 encoder (an archive made by liblz4 years ago).  appendBlockList walks the frame's size words
+ * once on the host (a 4-byte read per block, no GPU) and writes, at buf + frameSize, the skippable frame lz4f_mi355x_dev_decompressFrame
+ * looks for at a stream's end: where every block's size word is.  The device decoder then checks those positions link by link in parallel
+ * instead of walking them - a walk is one dependent read per block, 0.12 ms for 256 blocks of 4 MiB and 10x that for 64 KiB blocks - and
+ * every other LZ4 reader skips the extra frame as the format says.  frameSize must be exactly the frame (header .. EndMark / content
+ * checksum); returns frameSize + the bytes added (nothing is added to a frame without blocks), or an error code
+ * (dstMaxSize_tooSmall: capacity; frameSize_wrong: the frame does not end at frameSize).  blockListSize: the bytes appendBlockList would add.
+ * The frame must start 16-byte aligned in DEVICE memory when it is decoded for the list to be looked at (it is a hint: without it the
+ * walk happens as before). */
+LZ4F_MI355X_API size_t lz4f_mi355x_blockListSize(const void* frame, size_t frameSize);
+LZ4F_MI355X_API size_t lz4f_mi355x_appendBlockList(void* buf, size_t frameSize, size_t capacity);
 /* Decodes the first frame found in src. *srcConsumed (optional) = bytes of src used. */
 LZ4F_MI355X_API size_t lz4f_mi355x_decompressFrame(void* dst, size_t dstCapacity, const void* src, size_t srcSize,
                                                    size_t* srcConsumed);
@@ -331,6 +343,10 @@ LZ4F_MI355X_API int lz4f_mi355x_conduit_decompress(lz4f_mi355x_await_fn await, l
                                                  char* errbuf, size_t errcap);
 /* batched conduits (new): gather >= batchBytes of input per GPU call */
 LZ4F_MI355X_API int lz4f_mi355x_conduit_compress_batched(size_t batchBytes, const LZ4F_preferences_t* prefs,
+                                                 lz4f_mi355x_await_fn await, lz4f_mi355x_yield_fn yield, void* user,
+                                                 char* errbuf, size_t errcap);
+/* the same, and behind the frame its BLOCK LIST as a skippable frame (see lz4f_mi355x_appendBlockList): `mi355x-lz4c --index` */
+LZ4F_MI355X_API int lz4f_mi355x_conduit_compress_batched_listed(size_t batchBytes, const LZ4F_preferences_t* prefs,
                                                  lz4f_mi355x_await_fn await, lz4f_mi355x_yield_fn yield, void* user,
                                                  char* errbuf, size_t errcap);
 LZ4F_MI355X_API int lz4f_mi355x_conduit_decompress_batched(lz4f_mi355x_await_fn await, lz4f_mi355x_yield_fn yield, void* user,

@@ -86,6 +86,8 @@ _SIGS = {
     "lz4f_mi355x_conduit_compress_yield_immediately": (ctypes.c_int, [PP, AWAIT_FN, YIELD_FN, c_void_p, ctypes.c_char_p, c_size_t]),
     "lz4f_mi355x_conduit_decompress": (ctypes.c_int, [AWAIT_FN, YIELD_FN, c_void_p, ctypes.c_char_p, c_size_t]),
     "lz4f_mi355x_conduit_compress_batched": (ctypes.c_int, [c_size_t, PP, AWAIT_FN, YIELD_FN, c_void_p, ctypes.c_char_p, c_size_t]),
+    "lz4f_mi355x_conduit_compress_batched_listed": (ctypes.c_int, [c_size_t, PP, AWAIT_FN, YIELD_FN, c_void_p, ctypes.c_char_p, c_size_t]),
+    "lz4f_mi355x_blockListSize": (c_size_t, [c_void_p, c_size_t]), "lz4f_mi355x_appendBlockList": (c_size_t, [c_void_p, c_size_t, c_size_t]),
     "lz4f_mi355x_conduit_decompress_batched": (ctypes.c_int, [AWAIT_FN, YIELD_FN, c_void_p, ctypes.c_char_p, c_size_t]),
 }
 DECLARED_SYMBOLS = tuple(_SIGS)

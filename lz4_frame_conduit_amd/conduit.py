@@ -96,8 +96,22 @@ def decompress(chunks: Iterable[bytes]) -> List[bytes]:                         
     return _run("lz4f_mi355x_conduit_decompress", chunks)
 
 
-def compressBatched(chunks: Iterable[bytes], prefs: Optional[Preferences] = None, batchBytes: int = 64 << 20) -> List[bytes]:
-    return _run("lz4f_mi355x_conduit_compress_batched", chunks, batchBytes, _p(prefs))
+def compressBatched(chunks: Iterable[bytes], prefs: Optional[Preferences] = None, batchBytes: int = 64 << 20, blockList: bool = False) -> List[bytes]:
+    """blockList: the frame's block list follows it as a skippable frame (include/lz4f_mi355x.h: lz4f_mi355x_appendBlockList)."""
+    return _run("lz4f_mi355x_conduit_compress_batched_listed" if blockList else "lz4f_mi355x_conduit_compress_batched", chunks, batchBytes, _p(prefs))
+
+
+def appendBlockList(frame: bytes) -> bytes:
+    """A finished LZ4 frame (any encoder's) + its block list as a skippable frame; host work only (no GPU)."""
+    L = _ffi.lib()
+    need = L.lz4f_mi355x_blockListSize(frame, len(frame))
+    if L.LZ4F_isError(need):
+        raise Lz4FrameError("lz4frame error: " + L.LZ4F_getErrorName(need).decode())
+    buf = ctypes.create_string_buffer(frame, len(frame) + need)
+    r = L.lz4f_mi355x_appendBlockList(buf, len(frame), len(frame) + need)
+    if L.LZ4F_isError(r):
+        raise Lz4FrameError("lz4frame error: " + L.LZ4F_getErrorName(r).decode())
+    return buf.raw[:r]
 
 
 def decompressBatched(chunks: Iterable[bytes]) -> List[bytes]:

@@ -208,7 +208,7 @@ struct Pinned {
     ~Pinned() { lz4f_mi355x_host_free(p); }
 };
 }
-void compressBatched(size_t batchBytes, const LZ4F_preferences_t* prefsIn, const Await& await, const Yield& yield)
+void compressBatched(size_t batchBytes, const LZ4F_preferences_t* prefsIn, const Await& await, const Yield& yield, bool blockList)
 {
     LZ4F_preferences_t prefs; memset(&prefs, 0, sizeof(prefs));
     if (prefsIn) prefs = *prefsIn;
@@ -228,6 +228,8 @@ void compressBatched(size_t batchBytes, const LZ4F_preferences_t* prefsIn, const
     in.ensure(HIST + batchBytes + bs + (1u << 20));              // [64 KiB of the batch before][this batch ...]
     size_t fill = 0, hist = 0;                                  // bytes gathered behind in.p + HIST; valid history in front of them
     uint64_t total = 0;
+    uint64_t framePos = headerSize;                              // where the next batch's blocks land in the frame
+    BlockList bl;                                                // blockList: every block's size word, for the trailer behind the frame
     Xxh32State xxh; xxh.reset(0);
     auto flushBatch = [&](bool last) {
         const size_t n = last ? fill : (fill / bs) * bs;         // whole blocks; at the end also the short one
@@ -236,6 +238,8 @@ void compressBatched(size_t batchBytes, const LZ4F_preferences_t* prefsIn, const
         out.ensure(cap);
         size_t w = 0;
         handleLz4Error(pipe_compress_blocks(in.p + HIST, n, (uint32_t)bs, linked, bck, out.p, out.cap, &w, hist));
+        if (blockList && !bl.add_blocks(out.p, w, framePos, bck)) handleLz4Error(make_err(LZ4F_ERROR_GENERIC));
+        framePos += w;
         if (w) yield(Slice{out.p, w});
         if (linked) { const size_t keep = std::min(HIST, hist + n); memmove(in.p + HIST - keep, in.p + HIST + n - keep, keep); hist = keep; }
         memmove(in.p + HIST, in.p + HIST + n, fill - n);
@@ -260,6 +264,16 @@ void compressBatched(size_t batchBytes, const LZ4F_preferences_t* prefsIn, const
     if (cck) { const uint32_t d = xxh.digest(); tail[4] = (uint8_t)d; tail[5] = (uint8_t)(d >> 8); tail[6] = (uint8_t)(d >> 16); tail[7] = (uint8_t)(d >> 24); tn = 8; }
     yield(Slice{tail, tn});
     if (prefs.frameInfo.contentSize && prefs.frameInfo.contentSize != total) handleLz4Error(make_err(LZ4F_ERROR_frameSize_wrong));
+    if (blockList && !bl.at.empty()) {
+        // a skippable frame behind the LZ4 frame (frame_dev.cuh: the trailer): any LZ4 reader skips it; lz4f_mi355x_dev_decompressFrame
+        // finds the size words through it instead of walking them
+        const uint64_t F = framePos + tn;
+        const size_t tsz = host_trailer_size(F, bl.at.size());
+        handleLz4Error(tsz);
+        std::vector<uint8_t> tr(tsz);
+        host_write_trailer(tr.data(), F, bl.at.data(), (uint32_t)bl.at.size());
+        yield(Slice{tr.data(), tr.size()});
+    }
 }
 
 // decompressBatched: gathers the stream and decodes each frame's blocks through the bulk path
@@ -357,6 +371,11 @@ int lz4f_mi355x_conduit_compress_batched(size_t batchBytes, const LZ4F_preferenc
                                          void* user, char* errbuf, size_t errcap)
 {
     return guarded(errbuf, errcap, [&] { compressBatched(batchBytes, prefs, wrap_await(a, user), wrap_yield(y, user)); });
+}
+int lz4f_mi355x_conduit_compress_batched_listed(size_t batchBytes, const LZ4F_preferences_t* prefs, lz4f_mi355x_await_fn a, lz4f_mi355x_yield_fn y,
+                                                void* user, char* errbuf, size_t errcap)
+{
+    return guarded(errbuf, errcap, [&] { compressBatched(batchBytes, prefs, wrap_await(a, user), wrap_yield(y, user), true); });
 }
 int lz4f_mi355x_conduit_decompress_batched(lz4f_mi355x_await_fn a, lz4f_mi355x_yield_fn y, void* user, char* errbuf, size_t errcap)
 {

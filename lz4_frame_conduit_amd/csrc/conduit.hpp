@@ -24,7 +24,7 @@ void compressWithOutBufferSize(size_t bufferSize, const LZ4F_preferences_t* pref
 void decompress(const Await&, const Yield&);                                                   // Conduit.hsc:598-701
 // additions: preferences as a parameter, and batched drivers for the GPU
 void compressWithPreferences(const LZ4F_preferences_t& prefs, const Await&, const Yield&);
-void compressBatched(size_t batchBytes, const LZ4F_preferences_t* prefs, const Await&, const Yield&);
+void compressBatched(size_t batchBytes, const LZ4F_preferences_t* prefs, const Await&, const Yield&, bool blockList = false);
 void decompressBatched(const Await&, const Yield&);
 
 }  // namespace conduit

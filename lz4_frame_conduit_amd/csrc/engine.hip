@@ -1008,6 +1008,43 @@ size_t lz4f_mi355x_engine::decompress_frame_host(const uint8_t* s, size_t n, con
     return 0;
 }
 
+// ---- the trailer's block list made on the host (same bytes k_trailer_plan / k_trailer_copy write for a frame without a sequence index) ----
+namespace lz4f {
+bool BlockList::add_blocks(const uint8_t* b, size_t n, uint64_t frame_off, bool bck)
+{
+    size_t pos = 0;
+    while (pos < n) {
+        if (n - pos < 4) return false;
+        const uint32_t w = (uint32_t)b[pos] | ((uint32_t)b[pos + 1] << 8) | ((uint32_t)b[pos + 2] << 16) | ((uint32_t)b[pos + 3] << 24);
+        const size_t step = 4 + (size_t)(w & 0x7FFFFFFFu) + (bck ? 4 : 0);
+        if (w == 0 || step > n - pos) return false;
+        at.push_back(frame_off + pos);
+        pos += step;
+    }
+    return true;
+}
+size_t host_trailer_size(uint64_t F, uint64_t n_blocks)
+{
+    if (n_blocks == 0) return 0;
+    if (n_blocks > 0x7FFFFFFFull) return make_err(LZ4F_ERROR_frameSize_wrong);
+    const uint64_t list_at = (F + 8 + 15) & ~(uint64_t)15, n_list = (n_blocks + 1) & ~1ull;
+    const uint64_t total = list_at + n_list * 8 + sizeof(TrailerFoot) - F;
+    if (total - 8 >= 0xFFFFFFFFull) return make_err(LZ4F_ERROR_frameSize_wrong);        // (a skippable frame's size field is 32 bits)
+    return (size_t)total;
+}
+void host_write_trailer(uint8_t* t, uint64_t F, const uint64_t* at, uint32_t n_blocks)
+{
+    const uint64_t list_at = (F + 8 + 15) & ~(uint64_t)15, n_list = ((uint64_t)n_blocks + 1) & ~1ull, ix_at = list_at + n_list * 8;
+    const uint64_t total = ix_at + sizeof(TrailerFoot) - F;
+    const uint32_t sz = (uint32_t)(total - 8);
+    t[0] = 0x5E; t[1] = 0x2A; t[2] = 0x4D; t[3] = 0x18; t[4] = (uint8_t)sz; t[5] = (uint8_t)(sz >> 8); t[6] = (uint8_t)(sz >> 16); t[7] = (uint8_t)(sz >> 24);
+    memset(t + 8, 0, (size_t)(list_at - F - 8));
+    for (uint64_t i = 0; i < n_list; i++) { const uint64_t v = i < n_blocks ? at[i] : 0; memcpy(t + (list_at - F) + i * 8, &v, 8); }
+    const TrailerFoot f{0u, 0u, 0u, 0u, TR_FOOT, n_blocks, total};
+    memcpy(t + (ix_at - F), &f, sizeof(f));
+}
+}  // namespace lz4f
+
 // ------------------------------------------------------------------------------------------------
 // C ABI: engine + device-pointer entry points
 extern "C" {

@@ -166,4 +166,14 @@ size_t pipe_compress_blocks(const uint8_t* src, size_t n, uint32_t block_size, b
 size_t pipe_decompress_frame(const uint8_t* frame, size_t n, const ParsedHeader& ph, uint8_t* flat, size_t flat_cap,
                              const std::function<void(const uint8_t*, size_t)>* sink, size_t* decoded, size_t* consumed);
 uint32_t pick_chunk_size(uint32_t block_size);
+// The block-list trailer (frame_dev.cuh: the trailer) made on the host, for frames the host paths assemble or are handed:
+// `at` = where every block's size word is in the frame.  host_trailer_size: the bytes it takes behind a frame of frame_size bytes
+// (0 without blocks, an error code beyond what a skippable frame can say); host_write_trailer writes them at `dst` (= frame + frame_size).
+struct BlockList {
+    std::vector<uint64_t> at;
+    // the size words of whole blocks lying in blocks[0..n), which sit at frame_off in the frame; false when they do not tile n bytes
+    bool add_blocks(const uint8_t* blocks, size_t n, uint64_t frame_off, bool block_checksum);
+};
+size_t host_trailer_size(uint64_t frame_size, uint64_t n_blocks);
+void   host_write_trailer(uint8_t* dst, uint64_t frame_size, const uint64_t* at, uint32_t n_blocks);
 }

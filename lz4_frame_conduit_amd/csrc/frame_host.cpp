@@ -751,6 +751,56 @@ size_t lz4f_mi355x_compressFrame(void* dst, size_t dstCapacity, const void* src,
     return used;
 }
 
+// ---- the block list of a finished frame in host memory (ours or any other encoder's), as the trailer the device decoder looks for ----
+// (host work only: one 4-byte read per block)
+static size_t walk_for_block_list(const uint8_t* s, size_t n, BlockList* bl)
+{
+    if (n < 7) return make_err(LZ4F_ERROR_frameHeader_incomplete);
+    ParsedHeader ph;
+    const size_t hs = parse_frame_header(s, n, &ph);                    // (a skippable frame is frameType_unknown here: nothing to list)
+    if (is_err(hs)) return hs;
+    const size_t crc = ph.info.blockChecksumFlag ? 4 : 0;
+    size_t pos = ph.header_size;
+    for (;;) {
+        if (n - pos < 4) return make_err(LZ4F_ERROR_frameHeader_incomplete);
+        const uint32_t w = le32(s + pos);
+        if (w == 0) break;
+        const size_t csz = w & 0x7FFFFFFFu;
+        if (csz > ph.max_block) return make_err(LZ4F_ERROR_maxBlockSize_invalid);
+        if (n - pos - 4 < csz + crc) return make_err(LZ4F_ERROR_frameHeader_incomplete);
+        bl->at.push_back(pos);
+        pos += 4 + csz + crc;
+    }
+    pos += 4;
+    if (ph.info.contentChecksumFlag) { if (n - pos < 4) return make_err(LZ4F_ERROR_frameHeader_incomplete); pos += 4; }
+    if (pos != n) { set_last_error("block list: the frame ends at %zu, not at frameSize %zu", pos, n); return make_err(LZ4F_ERROR_frameSize_wrong); }
+    return 0;
+}
+size_t lz4f_mi355x_blockListSize(const void* frame, size_t frameSize)
+{
+    try {
+        BlockList bl;
+        const size_t r = walk_for_block_list((const uint8_t*)frame, frameSize, &bl);
+        if (is_err(r)) return r;
+        return host_trailer_size(frameSize, bl.at.size());
+    } catch (const std::exception& e) { set_last_error("blockListSize: %s", e.what()); return make_err(LZ4F_ERROR_allocation_failed); }
+}
+size_t lz4f_mi355x_appendBlockList(void* buf, size_t frameSize, size_t capacity)
+{
+    try {
+        if (capacity < frameSize) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
+        BlockList bl;
+        size_t r = walk_for_block_list((const uint8_t*)buf, frameSize, &bl);
+        if (is_err(r)) return r;
+        r = host_trailer_size(frameSize, bl.at.size());
+        if (is_err(r)) return r;
+        if (r == 0) return frameSize;                                   // no block, no list
+        if (capacity - frameSize < r) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
+        host_write_trailer((uint8_t*)buf + frameSize, frameSize, bl.at.data(), (uint32_t)bl.at.size());
+        return frameSize + r;
+    } catch (const std::exception& e) { set_last_error("appendBlockList: %s", e.what()); return make_err(LZ4F_ERROR_allocation_failed); }
+}
+
 static size_t decompress_frame_common(void* dst, size_t dstCapacity, const void* src, size_t srcSize, size_t* srcConsumed,
                                       const std::function<void(const uint8_t*, size_t)>* sink)
 {

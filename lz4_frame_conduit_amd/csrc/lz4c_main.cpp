@@ -3,7 +3,8 @@
 // the file streamed through `compress` / `decompress`.  Additions: -B4..-B7 (block size ID),
 // -BI / -BD (independent / linked blocks), --block-checksum, --content-checksum, --batch MiB (gather that much input per
 // GPU call; 0 = the reference's 16 KiB-slice conduit verbatim).  Frames are standard LZ4 frames: interchangeable with
-// the `lz4` CLI in both directions.
+// the `lz4` CLI in both directions.  --index: the frame's block list follows it as a skippable frame (lz4f_mi355x_appendBlockList's
+// format; other readers skip it, the device decoder finds the blocks through it).
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,7 +16,7 @@
 static void usage(FILE* f)
 {
     fputs("Usage: mi355x-lz4c [INPUT_FILE] [OUTPUT-FILE] [-d|--decompress] [-B4|-B5|-B6|-B7] [-BI|-BD]\n"
-          "                   [--block-checksum] [--content-checksum] [--batch MiB]\n"
+          "                   [--block-checksum] [--content-checksum] [--batch MiB] [--index]\n"
           "  Compress or decompress .lz4 files\n", f);
 }
 
@@ -37,7 +38,7 @@ static void yield_cb(void* user, const void* data, size_t size)
 int main(int argc, char** argv)
 {
     std::vector<std::string> pos;
-    bool dec = false;
+    bool dec = false, listed = false;
     size_t batch = (size_t)64 << 20;
     LZ4F_preferences_t prefs; memset(&prefs, 0, sizeof(prefs));     // = lz4DefaultPreferences (Conduit.hsc:248-263): 64 KiB linked blocks, no checksums
     prefs.frameInfo.blockSizeID = LZ4F_max64KB;
@@ -50,6 +51,7 @@ int main(int argc, char** argv)
         else if (a == "-BD") prefs.frameInfo.blockMode = LZ4F_blockLinked;
         else if (a == "--block-checksum") prefs.frameInfo.blockChecksumFlag = LZ4F_blockChecksumEnabled;
         else if (a == "--content-checksum") prefs.frameInfo.contentChecksumFlag = LZ4F_contentChecksumEnabled;
+        else if (a == "--index") listed = true;
         else if (a == "--batch" && i + 1 < argc) batch = (size_t)strtoull(argv[++i], nullptr, 10) << 20;
         else if (a == "-" || a[0] != '-') pos.push_back(a);
         else { usage(stderr); return 2; }
@@ -64,7 +66,9 @@ int main(int argc, char** argv)
     int rc;
     if (dec) rc = batch ? lz4f_mi355x_conduit_decompress_batched(await_cb, yield_cb, &io, err, sizeof(err))
                         : lz4f_mi355x_conduit_decompress(await_cb, yield_cb, &io, err, sizeof(err));
-    else     rc = batch ? lz4f_mi355x_conduit_compress_batched(batch, &prefs, await_cb, yield_cb, &io, err, sizeof(err))
+    else if (listed && !batch) { fputs("mi355x-lz4c: --index needs --batch > 0\n", stderr); return 2; }
+    else     rc = listed ? lz4f_mi355x_conduit_compress_batched_listed(batch, &prefs, await_cb, yield_cb, &io, err, sizeof(err))
+               : batch ? lz4f_mi355x_conduit_compress_batched(batch, &prefs, await_cb, yield_cb, &io, err, sizeof(err))
                         : lz4f_mi355x_conduit_compress(0, &prefs, await_cb, yield_cb, &io, err, sizeof(err));
     if (rc != 0) { fprintf(stderr, "mi355x-lz4c: %s\n", err[0] ? err : "failed"); return 1; }
     if (io.write_failed || fflush(io.out) != 0) { fputs("mi355x-lz4c: write failed\n", stderr); return 1; }

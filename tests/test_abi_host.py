@@ -171,3 +171,45 @@ def test_cli_builds_and_fails_loudly_without_gpu(L):
         pytest.skip("a GPU is present")
     p = subprocess.run([cli], input=b"x" * 100000, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
     assert p.returncode == 1 and b"ERROR_GENERIC" in p.stderr
+
+
+def test_block_list_of_a_finished_frame_is_host_work(L):
+    """lz4f_mi355x_appendBlockList (include/lz4f_mi355x.h) walks a frame's size words on the host and appends the skippable
+    frame the device decoder looks for: no GPU involved, any encoder's frame.  Checked here: the layout (magic, size field,
+    16-byte aligned list of size-word positions, footer in the last 32 bytes), that the frame in front is untouched and that
+    an LZ4 reader (the oracle, and liblz4 when installed) still reads it and sees one skippable frame behind it; the GPU
+    side of it (the device decoder using the list) is tests/test_gpu_parity.py::test_block_list_trailer_from_the_host_paths."""
+    import struct
+    import oracle
+    from lz4_frame_conduit_amd import datagen
+    data = datagen.structured(300000, 5)
+    for kw in (dict(bsid=4, indep=1), dict(bsid=4, indep=0, bck=1, cck=1), dict(bsid=5, indep=1, cck=1)):
+        frame = oracle.conduit_compress(data, oracle.mkprefs(**kw))
+        listed = conduit.appendBlockList(frame)
+        assert listed[:len(frame)] == frame and len(listed) > len(frame)
+        F = len(frame)
+        assert listed[F:F + 4] == bytes.fromhex("5e2a4d18") and struct.unpack_from("<I", listed, F + 4)[0] == len(listed) - F - 8
+        seqs, ents, p0, p1, magic, n_blocks, total = struct.unpack_from("<6IQ", listed, len(listed) - 32)
+        assert (seqs, ents, p0, p1) == (0, 0, 0, 0) and magic == 0x58495A4C and total == len(listed) - F
+        list_at = (F + 8 + 15) & ~15
+        at = struct.unpack_from("<%dQ" % n_blocks, listed, list_at)
+        crc = 4 if kw.get("bck") else 0
+        pos = 7
+        for a in at:                                       # every entry is a size word, each where the one before ends
+            assert a == pos
+            pos += 4 + (struct.unpack_from("<I", frame, a)[0] & 0x7FFFFFFF) + crc
+        assert struct.unpack_from("<I", frame, pos)[0] == 0 and n_blocks == -(-len(data) // (65536 << (2 * (kw["bsid"] - 4))))
+        out, used = oracle.decompress_frame(listed)
+        assert out == data and used == F
+        out2, used2 = oracle.decompress_frame(listed[F:])
+        assert out2 == b"" and used2 == len(listed) - F    # a skippable frame: nothing decoded, all of it consumed
+    # a frame without blocks gets nothing; a frame that does not end where the caller says is refused; so is too little room
+    empty = oracle.conduit_compress(b"", oracle.mkprefs())
+    assert conduit.appendBlockList(empty) == empty
+    frame = oracle.conduit_compress(data, oracle.mkprefs(bsid=4, indep=1))
+    for bad in (frame + b"\0", frame[:-1]):
+        r = L.lz4f_mi355x_blockListSize(bad, len(bad))
+        assert L.LZ4F_isError(r)
+    buf = ctypes.create_string_buffer(frame, len(frame) + 16)
+    r = L.lz4f_mi355x_appendBlockList(buf, len(frame), len(frame) + 16)
+    assert L.LZ4F_isError(r) and L.LZ4F_getErrorName(r) == b"ERROR_dstMaxSize_tooSmall" and buf.raw[:len(frame)] == frame

@@ -864,6 +864,72 @@ def test_inband_trailer_interop_and_robustness(L):
 
 
 @pytest.mark.gpu
+def test_block_list_trailer_from_the_host_paths(L, tmp_path):
+    """The block list made on the HOST (lz4f_mi355x_appendBlockList over any finished frame; compressBatched(blockList=True); `mi355x-lz4c
+    --index`): the device decoder finds the size words through it (PATH trailer set, no walk of any kind), the bytes are the input's, every
+    other reader skips the extra frame, and a list that lies is only a hint that fails its check."""
+    import subprocess
+    import torch
+    from lz4_frame_conduit_amd.device import Engine
+    eng = Engine(0)
+    P = PATH
+    walks = P["parallel_walk"] | P["table"]
+
+    def dev_decode(stream: bytes, n_out: int):
+        dev = torch.zeros(len(stream) + 32, dtype=torch.uint8, device="cuda")
+        dev[:len(stream)] = torch.from_numpy(np.frombuffer(stream, dtype=np.uint8).copy()).cuda()
+        back = torch.zeros(n_out + 64, dtype=torch.uint8, device="cuda")
+        eng.decompress_frame_async(dev, len(stream), back)
+        r = eng.result()
+        return back[:r.size].cpu().numpy().tobytes(), r
+
+    data = datagen.synth50(24 << 20, 21)
+    raw = data.tobytes()
+    # (1) a foreign frame (the oracle's = liblz4's bytes), listed after the fact on the host
+    for kw in (dict(bsid=7, indep=1), dict(bsid=4, indep=1, bck=1), dict(bsid=4, indep=0, cck=1)):
+        frame = oracle.conduit_compress(raw, oracle.mkprefs(**kw))
+        plain_out, plain_r = dev_decode(frame, len(raw))
+        assert plain_out == raw and not ((plain_r.flags >> 12) & P["trailer"])
+        listed = conduit.appendBlockList(frame)
+        out, r = dev_decode(listed, len(raw))
+        path = r.flags >> 12
+        assert out == raw and r.consumed == len(frame), kw
+        assert (path & P["trailer"]) and not (path & walks), (kw, hex(path))
+        # a lying list: one entry moved, the count changed - the check fails, the frame is walked, the bytes are still right
+        n_blocks = int.from_bytes(listed[-12:-8], "little")
+        list_at = (len(frame) + 8 + 15) & ~15
+        for trial in range(3):
+            bad = bytearray(listed)
+            if trial == 0: bad[list_at + 8 * (n_blocks // 2)] ^= 0x10
+            elif trial == 1: bad[-12:-8] = (n_blocks - 1).to_bytes(4, "little")
+            else: bad[list_at:list_at + 8] = (3).to_bytes(8, "little")
+            out, r = dev_decode(bytes(bad), len(raw))
+            assert out == raw and r.consumed == len(frame), (kw, trial)
+    # (2) the batched conduit with the list, and the readers that do not know it
+    p = conduit.make_preferences(blockSizeID=7, blockMode=1)
+    stream = b"".join(conduit.compressBatched([raw[:5_000_000], raw[5_000_000:]], p, batchBytes=8 << 20, blockList=True))
+    out, used = oracle.decompress_frame(stream, cap=len(raw) + 64)
+    assert out == raw and stream[used:used + 4] == bytes.fromhex("5e2a4d18")
+    assert conduit.appendBlockList(stream[:used]) == stream                   # the same bytes the host walk of the finished frame gives
+    assert b"".join(conduit.decompressBatched([stream])) == raw and b"".join(conduit.decompress([stream])) == raw
+    out, r = dev_decode(stream, len(raw))
+    assert out == raw and ((r.flags >> 12) & P["trailer"]) and not ((r.flags >> 12) & walks)
+    # (3) the command-line driver
+    cli = os.path.join(os.path.dirname(_ffi.LIB_PATH), "mi355x-lz4c")
+    fin, fz, fback = tmp_path / "in.bin", tmp_path / "in.lz4", tmp_path / "back.bin"
+    fin.write_bytes(raw[:9_000_000])
+    subprocess.run([cli, str(fin), str(fz), "-B6", "-BI", "--index", "--batch", "4"], check=True, timeout=300)
+    z = fz.read_bytes()
+    out, used = oracle.decompress_frame(z, cap=9_000_000 + 64)
+    assert out == raw[:9_000_000] and used < len(z) and conduit.appendBlockList(z[:used]) == z
+    subprocess.run([cli, "-d", str(fz), str(fback)], check=True, timeout=300)
+    assert fback.read_bytes() == raw[:9_000_000]
+    out, r = dev_decode(z, 9_000_000)
+    assert out == raw[:9_000_000] and ((r.flags >> 12) & P["trailer"])
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_soak_and_fuzz_slices():
     """A slice of the development soak (tools/soak_indexed.py: random shapes compressed, then decoded with, without and again with the
     index) and of the mutation fuzz (tools/fuzz_linked.py: single-byte mutations, verdicts and bytes against the oracle) on every run
