@@ -313,6 +313,12 @@ LZ4F_MI355X_API size_t lz4f_mi355x_dev_index_size(size_t srcSize, const LZ4F_pre
 #define LZ4F_MI355X_PATH_FUSED         0x100u   /* fused parse+copy workgroups were launched (alone, or as what the others fall back to) */
 #define LZ4F_MI355X_PATH_WAVE_PER_BLOCK 0x200u  /* small independent blocks: a wave per block */
 #define LZ4F_MI355X_PATH_INDEX_DROPPED 0x400u   /* set on the device: the indexed kernels refused the index, the generic ones decoded */
+/* compress calls, result.flags bit 9: the encoder's record workspace (sized for a sequence per 5.3 input bytes on average - dense text has
+ * one per 6..8 - instead of the format's worst case of one per 4: lz4f_mi355x_dev_workspace_size) was used up, and the 64 KiB tiles that
+ * found it empty went out as literals.  The frame is valid and decodes to the input, it is only bigger than it could be.
+ * LZ4F_MI355X_RECS_PER_TILE (1..16385 records per 64 KiB of input, read when an engine is made; default 12288 = 1.5 bytes of workspace
+ * per input byte, 16385 = worst case for every tile, 1024 = 0.13 bytes per byte for data known to be sparse in matches) sizes it. */
+#define LZ4F_MI355X_ENC_POOL_SHORT     0x200u
 LZ4F_MI355X_API size_t lz4f_mi355x_trailer_bound(size_t srcSize, const LZ4F_preferences_t* prefs);
 LZ4F_MI355X_API size_t lz4f_mi355x_dev_compressFrameIndexed(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize,
                                                             const LZ4F_preferences_t* prefs, lz4f_mi355x_result* d_result,

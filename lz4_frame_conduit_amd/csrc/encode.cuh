@@ -24,6 +24,7 @@
 namespace lz4f {
 
 constexpr uint32_t MFLIMIT = 12, LASTLIT = 5, MINMATCH = 4;
+constexpr uint32_t ENC_POOL_SHORT = 0x200u;      // result.flags (LZ4F_MI355X_ENC_POOL_SHORT): tiles went out as literals because the record pool was used up
 
 struct ChunkInfo {           // 32 bytes, one per chunk
     uint32_t nrec;           // sequence records found
@@ -48,11 +49,21 @@ struct EncGeom {
     uint32_t block_checksum;
     uint32_t header_size;
     uint8_t  header[20];
-    uint32_t max_rec_per_chunk;  // record slots per chunk
+    uint32_t max_rec_per_chunk;  // the most records a chunk can have (one per 4 bytes)
+    uint64_t rec_pool;           // records the pool holds (rec_pool_of): the tiles' lists are allocated from it as they are merged
     uint32_t seed_stride;        // pass E1: a run's 64 KiB of history go into the table at every seed_stride-th position
     uint32_t tiles_per_wg;       // pass E1: consecutive chunks a workgroup takes
     uint32_t e1_solo;            // (development) pass E1: bit 0 - only the workgroup's first wave parses (the sequential parse, for comparing ratios); bit 1 - nothing is parsed (the cost of everything else)
 };
+
+// The record workspace: [control: bump pointer, tiles that found the pool empty | u32 per chunk: where its list starts | the pool].
+// A tile's list is allocated when its merge knows how long it is - the workspace is sized for what inputs have (the engine: a record per
+// 5.3 input bytes by default), not for one per 4 bytes everywhere; a tile that finds the pool empty is emitted as literals (valid, bigger)
+// and counted.
+__device__ __forceinline__ unsigned long long* rec_ctl(const uint64_t* recs) { return (unsigned long long*)recs; }
+__device__ __forceinline__ uint32_t* rec_offs(const uint64_t* recs) { return (uint32_t*)(recs + 8); }
+__host__ __device__ __forceinline__ uint64_t rec_pool_at(uint32_t n_chunks) { return 8 + (((uint64_t)n_chunks + 1 + 15) / 16) * 8; }      // in records (8 bytes)
+__device__ __forceinline__ uint64_t* rec_pool_of(const uint64_t* recs, const EncGeom& g) { return (uint64_t*)recs + rec_pool_at(g.n_chunks); }
 
 __device__ __forceinline__ uint32_t len_ext_bytes(uint32_t v) { return v >= 15 ? (v - 15) / 255 + 1 : 0; }
 __device__ __forceinline__ uint32_t seq_size(uint32_t lit, uint32_t mlen)
@@ -369,9 +380,16 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
         const uint32_t btot = wave_sum(body);
         const uint64_t has = __ballot(kept != 0);
         const uint32_t tile_first = has ? (uint32_t)__builtin_amdgcn_readlane(f_lit, (int)__builtin_ctzll(has)) : 0u;
+        // the list's place in the pool
+        unsigned long long base = 0;
+        if (lane == 0 && ktot) base = atomicAdd(rec_ctl(recs), (unsigned long long)ktot);
+        base = ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(base >> 32)) << 32) | __builtin_amdgcn_readfirstlane((uint32_t)base);
+        const bool room = base + ktot <= g.rec_pool;                     // (wave-uniform)
+        if (!room && lane == 0) atomicAdd(rec_ctl(recs) + 1, 1ull);
         // second walk: the kept records, literal runs counted from the kept match in front
-        {
-            uint64_t* out = recs + (uint64_t)c * g.max_rec_per_chunk + off;
+        if (room) {
+            if (lane == 0) rec_offs(recs)[c] = (uint32_t)base;
+            uint64_t* out = rec_pool_of(recs, g) + base + off;
             uint32_t cov = cov0, jn = 0, le = prev_end;
 #pragma unroll
             for (uint32_t j = 0; j < SP; j++) {
@@ -398,7 +416,8 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
         }
         ChunkInfo* ci = info + c;
         if (lane == 0) {
-            ci->nrec = ktot; ci->first_lit = tile_first; ci->tail_lit = te - kmax; ci->body_size = btot;
+            if (room) { ci->nrec = ktot; ci->first_lit = tile_first; ci->tail_lit = te - kmax; ci->body_size = btot; }
+            else      { ci->nrec = 0; ci->first_lit = 0; ci->tail_lit = te - ts; ci->body_size = 0; }      // no room for the list: the tile goes out as literals
             sh.mode = (uint64_t)ktot * 64 > (uint64_t)(te - ts) ? 2u : 1u;      // how the next tiles hand out their slices
         }
     };
@@ -831,7 +850,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_layout_blocks(EncGeom g, 
 
 // the scan over the blocks, header, EndMark, result record (one workgroup)
 __global__ __launch_bounds__(1024) void k_layout_scan(EncGeom g, BlockOut* __restrict__ table, const uint32_t* __restrict__ blk_bytes,
-                                                      uint8_t* __restrict__ dst, uint64_t dst_cap, ResultRec* __restrict__ res)
+                                                      uint8_t* __restrict__ dst, uint64_t dst_cap, ResultRec* __restrict__ res, const uint64_t* __restrict__ recs)
 {
     __shared__ uint64_t s_part[1024];
     __shared__ uint64_t s_carry;
@@ -862,7 +881,7 @@ __global__ __launch_bounds__(1024) void k_layout_scan(EncGeom g, BlockOut* __res
     }
     if (t == 0 && res) {
         res->size = fits ? frame_size : 0; res->consumed = g.src_size - g.first_off;
-        res->status = fits ? ST_OK : ST_DSTSMALL; res->n_blocks = g.n_blocks; res->first_bad_block = 0xFFFFFFFFu; res->flags = g.header[4];
+        res->status = fits ? ST_OK : ST_DSTSMALL; res->n_blocks = g.n_blocks; res->first_bad_block = 0xFFFFFFFFu; res->flags = g.header[4] | ((g.n_chunks && rec_ctl(recs)[1]) ? ENC_POOL_SHORT : 0u);
     }
 }
 
@@ -1044,7 +1063,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_emit_gather(const uint8_t
         }
         return;
     }
-    const uint64_t* rec = recs + (uint64_t)chunk * g.max_rec_per_chunk;
+    const uint64_t* rec = rec_pool_of(recs, g) + (ci.nrec ? rec_offs(recs)[chunk] : 0u);
     uint64_t lp_off = cs_abs - ci.carry_in;                 // input offset of the pending literal run
     uint64_t o_off = ci.out_off;                            // frame offset of the next token
     IxEntry* ent = nullptr; uint32_t ent_seq0 = 0, ent_last = 0; uint64_t pay0 = 0;

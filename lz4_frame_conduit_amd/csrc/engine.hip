@@ -93,6 +93,7 @@ void lz4f_mi355x_engine::Switches::read()
     if (on("LZ4F_MI355X_DETERMINISTIC")) e1_solo |= 1u;              // equal input -> equal bytes: one wave per workgroup parses, in order (see lz4f_mi355x_engine_set_deterministic)
     wait_ticks = 0; if (const char* v = getenv("LZ4F_MI355X_WAIT_TICKS")) { unsigned long long a = 0; if (sscanf(v, "%llu", &a) == 1) wait_ticks = a; }
     dblk_lds = 0; if (const char* v = getenv("LZ4F_MI355X_DBLK_LDS")) { const int k = atoi(v); if (k > 0 && k <= 150) dblk_lds = (unsigned)k << 10; }      // (development: fewer wave-per-block decoders per CU)
+    recs_per_tile = 0; if (const char* v = getenv("LZ4F_MI355X_RECS_PER_TILE")) { const int k = atoi(v); if (k >= 1 && k <= 16385) recs_per_tile = (unsigned)k; }
     seed = 2; if (const char* v = getenv("LZ4F_MI355X_SEED")) { unsigned a = 0; if (sscanf(v, "%u", &a) == 1 && a >= 1 && a <= 64) seed = a; }
 }
 namespace lz4f {
@@ -216,6 +217,20 @@ extern "C" __attribute__((visibility("default"))) int lz4f_mi355x_debug_prof(uns
     return hipMemcpy(out128, g_prof, 1024, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
 }
 
+// The record pool of one compress call, in records: `per_tile` a 64 KiB tile on average (0 = the default, 12288: a sequence per 5.3 input
+// bytes - the densest input of the tests, Zipf text, needs more than 8192 per tile; the bench input one per 2000), never less than 64 tiles' worst case
+// (small calls are sized for the worst case outright) and never more than the worst case.  LZ4F_MI355X_RECS_PER_TILE=16385 is the worst
+// case for every tile; a caller that knows its data is sparse sets it low (1024: 0.13 bytes of workspace per input byte).
+static uint64_t rec_pool_records(uint32_t n_chunks, uint32_t max_rec_per_chunk, unsigned per_tile)
+{
+    const uint64_t worst = (uint64_t)(n_chunks + 1) * max_rec_per_chunk;
+    uint64_t want = (uint64_t)(n_chunks + 1) * (per_tile ? per_tile : 12288u);
+    if (want < 64ull * max_rec_per_chunk) want = 64ull * max_rec_per_chunk;
+    if (want > worst) want = worst;
+    if (want > 0xFFFFFFF0ull) want = 0xFFFFFFF0ull;                      // (a list's place is a 32-bit record number)
+    return want;
+}
+
 size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst, uint64_t dst_cap,
                                            lz4f_mi355x_result* d_res, lz4f_mi355x_block* d_table, void* d_index, size_t index_cap)
 {    // in-band: the index is made in the engine's own buffer and copied, with the block list, into a skippable frame behind the
@@ -248,7 +263,8 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     g.seed_stride = sw.seed;
 
     if (info.ensure((size_t)(g.n_chunks + 1) * sizeof(ChunkInfo))) return make_err(LZ4F_ERROR_allocation_failed);
-    if (recs.ensure((size_t)(g.n_chunks + 1) * g.max_rec_per_chunk * 8)) return make_err(LZ4F_ERROR_allocation_failed);
+    g.rec_pool = rec_pool_records(g.n_chunks, g.max_rec_per_chunk, sw.recs_per_tile);
+    if (recs.ensure((size_t)(rec_pool_at(g.n_chunks) + g.rec_pool) * 8)) return make_err(LZ4F_ERROR_allocation_failed);
     if (blk_bytes.ensure((size_t)(g.n_blocks + 1) * 4)) return make_err(LZ4F_ERROR_allocation_failed);
     if (!d_table) { if (table.ensure((size_t)(g.n_blocks + 1) * sizeof(BlockOut))) return make_err(LZ4F_ERROR_allocation_failed); d_table = (lz4f_mi355x_block*)table.p; }
     if (res.ensure(sizeof(ResultRec) + sizeof(TrailerPlan) + 64)) return make_err(LZ4F_ERROR_allocation_failed);
@@ -273,6 +289,7 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
 #ifdef E1_DEBUG
             (void)hipMemsetAsync((uint8_t*)e1_scratch.p + (size_t)n_wg * 2 * E1_NSLICE * E1_REC_PER_SLICE * 8, 0, 2048, st);
 #endif
+            HIP_TRY(hipMemsetAsync(recs.p, 0, 64, st));                 // the pool's bump pointer and its count of tiles turned away
             hipLaunchKernelGGL(k_find_matches, dim3(n_wg), dim3(64 * E1_WAVES), 0, st, j.d_src, g, (ChunkInfo*)info.p, (uint64_t*)recs.p, (uint64_t*)e1_scratch.p);
             if (sw.e1_sync) (void)hipStreamSynchronize(st);
 #ifdef E1_DEBUG
@@ -287,7 +304,7 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     tick(1, false);
     {
         if (g.n_blocks) hipLaunchKernelGGL((k_layout_blocks<W>), dim3((g.n_blocks + W - 1) / W), dim3(64 * W), 0, st, g, (ChunkInfo*)info.p, (BlockOut*)d_table, (uint32_t*)blk_bytes.p);
-        hipLaunchKernelGGL(k_layout_scan, dim3(1), dim3(1024), 0, st, g, (BlockOut*)d_table, (const uint32_t*)blk_bytes.p, d_dst, dst_cap, (ResultRec*)d_res);
+        hipLaunchKernelGGL(k_layout_scan, dim3(1), dim3(1024), 0, st, g, (BlockOut*)d_table, (const uint32_t*)blk_bytes.p, d_dst, dst_cap, (ResultRec*)d_res, (const uint64_t*)recs.p);
         if (g.n_chunks) hipLaunchKernelGGL(k_layout_chunks, dim3((g.n_chunks + 255) / 256), dim3(256), 0, st, g, (ChunkInfo*)info.p, (const BlockOut*)d_table, d_dst, (const ResultRec*)d_res);
         if (d_index) {                                                            // sequence index for the indexed decoder
             if (g.n_blocks) hipLaunchKernelGGL((k_index_blocks<W>), dim3((g.n_blocks + W - 1) / W), dim3(64 * W), 0, st, g, (const ChunkInfo*)info.p, (const BlockOut*)d_table, (const ResultRec*)d_res, d_index, (uint64_t)index_cap);
@@ -1115,7 +1132,9 @@ size_t lz4f_mi355x_dev_workspace_size(size_t srcSize, const LZ4F_preferences_t* 
     if (!bs) return make_err(LZ4F_ERROR_maxBlockSize_invalid);
     uint32_t ch = pick_chunk_size((uint32_t)bs);
     size_t nchunks = (srcSize + bs - 1) / bs * (bs / ch) + 1;
-    return nchunks * (sizeof(ChunkInfo) + (size_t)(ch / 4 + 1) * 8) + ((srcSize + bs - 1) / bs + 1) * (sizeof(BlockOut) + 4) + 4096;
+    // (the record pool as an engine with default switches sizes it: 12288 records of 8 bytes per 64 KiB tile = 1.5 bytes per input byte)
+    return nchunks * sizeof(ChunkInfo) + (size_t)(rec_pool_at((uint32_t)nchunks) + rec_pool_records((uint32_t)nchunks, ch / 4 + 1, 0)) * 8
+           + ((srcSize + bs - 1) / bs + 1) * (sizeof(BlockOut) + 4) + 4096;
 }
 
 size_t lz4f_mi355x_dev_compressFrame(lz4f_mi355x_engine* e, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize,

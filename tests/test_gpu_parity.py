@@ -864,6 +864,58 @@ def test_inband_trailer_interop_and_robustness(L):
 
 
 @pytest.mark.gpu
+def test_encoder_record_pool_is_bounded_and_overflow_is_graceful(L):
+    """The match finder's record lists are allocated from a pool as the tiles are merged (csrc/encode.cuh: rec_ctl / rec_offs): sized for a
+    sequence per 5.3 input bytes by default (1.5 bytes of workspace per input byte instead of the worst case's 2) and by the caller's word
+    where the data is known (LZ4F_MI355X_RECS_PER_TILE=1024: 0.13 bytes per byte, enough for the bench input eight times over).  With the default pool neither the
+    bench input nor dense text nor the structured generators touch its end (result.flags bit 9 clear); with a pool made too small on purpose
+    (LZ4F_MI355X_RECS_PER_TILE) the tiles that find it empty go out as literals: flag set, frame still valid and still the input, only
+    bigger - never a wrong byte, never a write outside the pool."""
+    import torch
+    from lz4_frame_conduit_amd.device import Engine
+    POOL_SHORT = 0x200
+    text = datagen.synth_text(24 << 20, 3)
+    s50 = datagen.synth50(32 << 20, 4)
+    stru = np.frombuffer(datagen.structured(16 << 20, 8), dtype=np.uint8)
+    rep = np.frombuffer((b"abcdefg" * 10)[:64] * (16 << 14), dtype=np.uint8)             # short period: a sequence per few bytes where the parse is dense
+
+    def run(eng, data, kw):
+        src = torch.from_numpy(data.copy()).cuda()
+        p = prefs_of(kw)
+        frame = torch.empty(eng.frame_bound(src.numel(), p), dtype=torch.uint8, device="cuda")
+        eng.compress_async(src, frame, p)
+        r = eng.result()
+        stream = frame[:r.size].cpu().numpy().tobytes()
+        out, used = oracle.decompress_frame(stream, cap=len(data) + 64)
+        assert out == data.tobytes() and used == len(stream)
+        return r.size, r.flags
+
+    eng = Engine(0)
+    sizes = {}
+    for name, data in (("text", text), ("s50", s50), ("structured", stru), ("period", rep)):
+        for kw in (dict(bsid=7, indep=1), dict(bsid=4, indep=0)):
+            size, flags = run(eng, data, kw)
+            assert not (flags & POOL_SHORT), (name, kw)
+            sizes[(name, kw["bsid"])] = size
+    ws4g = L.lz4f_mi355x_dev_workspace_size(4 << 30, ctypes.byref(prefs_of(dict(bsid=7, indep=1))))
+    assert ws4g < 6.6e9, ws4g                                        # (round 2: 8.6 GB)
+    eng.close()
+    os.environ["LZ4F_MI355X_RECS_PER_TILE"] = "1024"                # a record per 64 bytes: text needs nine times that, the bench input a thirtieth
+    try:
+        small = Engine(0)
+    finally:
+        del os.environ["LZ4F_MI355X_RECS_PER_TILE"]
+    for name, data in (("text", text), ("s50", s50)):
+        for kw in (dict(bsid=7, indep=1), dict(bsid=4, indep=0)):
+            size, flags = run(small, data, kw)
+            if name == "text":
+                assert (flags & POOL_SHORT) and size > sizes[(name, kw["bsid"])], (name, kw)
+            else:
+                assert not (flags & POOL_SHORT) and abs(size - sizes[(name, kw["bsid"])]) < 0.01 * size, (name, kw)
+    small.close()
+
+
+@pytest.mark.gpu
 def test_block_list_trailer_from_the_host_paths(L, tmp_path):
     """The block list made on the HOST (lz4f_mi355x_appendBlockList over any finished frame; compressBatched(blockList=True); `mi355x-lz4c
     --index`): the device decoder finds the size words through it (PATH trailer set, no walk of any kind), the bytes are the input's, every
