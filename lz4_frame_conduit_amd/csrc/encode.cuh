@@ -1037,6 +1037,9 @@ __device__ __forceinline__ void emit_len_ext(uint8_t* p, uint32_t v /* value min
 // record its place in the payload and its literals' place in the input, each lane writes its own token / length bytes /
 // offset, and the literal runs of all 64 are copied by the lane-level gather of decode_fused.cuh (16-byte units found by
 // binary search over a prefix table in LDS, two rounds in flight), runs under 16 bytes with a lane per byte.
+#ifndef E2_V2
+#define E2_V2 1               // pass E2, long literal runs: the records' arithmetic in the lanes, 64 records at a time (0: the round 2 loop, all of it scalar)
+#endif
 template <int WAVES_PER_WG>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_emit_gather(const uint8_t* __restrict__ src, EncGeom g,
                                                                    const ChunkInfo* __restrict__ info, const uint64_t* __restrict__ recs,
@@ -1098,6 +1101,57 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_emit_gather(const uint8_t
     if ((uint64_t)ci.nrec * 192 <= ce_abs - cs_abs) {
         uint8_t* o = dst + o_off;
         const uint8_t* lp = src + lp_off;
+#if E2_V2
+        // The records' arithmetic - token, how many length bytes, their last one - for 64 records at once in the lanes; the trip per record
+        // gets four numbers by readlane and stores exactly what the loop below stores.  (Walked with everything wave-uniform, every record is
+        // computed on the scalar unit, divisions by 255 included: 220 scalar instructions per record, and a CU has one such unit - 88 %
+        // busy on the bench input, this kernel's limit there.)
+        for (uint32_t r0 = 0; r0 < ci.nrec; r0 += WAVE) {
+            const uint32_t rl = r0 + lane;
+            const uint64_t xr = rl < ci.nrec ? rec[rl] : 0ull;
+            uint32_t vlit = (uint32_t)(xr & 0xFFFFFFu);
+            const uint32_t vmlen = (uint32_t)((xr >> 24) & 0xFFFFFFu), voff = (uint32_t)(xr >> 48);
+            if (rl == 0) vlit += ci.carry_in;
+            const uint32_t vmcode = rl < ci.nrec ? vmlen - MINMATCH : 0u;
+            const uint32_t vhb = 1 + len_ext_bytes(vlit), vtb = 2 + len_ext_bytes(vmcode);
+            const uint32_t vtoken = ((vlit < 15 ? vlit : 15) << 4) | (vmcode < 15 ? vmcode : 15);
+            const uint32_t vlrest = vlit >= 15 ? (vlit - 15) % 255 : 0u, vmrest = vmcode >= 15 ? (vmcode - 15) % 255 : 0u;
+            const bool vbig = vhb > WAVE || vtb > WAVE;                    // (lengths of 16 KiB and more: the loop over their 255s)
+            const uint32_t vp1 = (vbig ? 0u : vhb | (vtb << 8)) | (vtoken << 16) | (vlrest << 24), vp2 = voff | (vmrest << 16), vadv = vlit + vmlen;
+            const uint32_t nb = ci.nrec - r0 < WAVE ? ci.nrec - r0 : WAVE;
+            for (uint32_t k = 0; k < nb; k++) {
+                const uint32_t r = r0 + k;
+                if (ent && (r % IX_STRIDE) == 0 && lane == 0) {
+                    uint32_t ns = ci.nrec - r < IX_STRIDE ? ci.nrec - r : IX_STRIDE;
+                    if (ent_last && r + IX_STRIDE >= ci.nrec) ns += 1;
+                    ent[r / IX_STRIDE] = IxEntry{(uint32_t)((uint64_t)(o - dst) - pay0), (uint32_t)((uint64_t)(lp - src) - bstart), ent_seq0 + r, ns | (blk << 8)};
+                }
+                const uint32_t lit = (uint32_t)__builtin_amdgcn_readlane((int)vlit, (int)k), adv = (uint32_t)__builtin_amdgcn_readlane((int)vadv, (int)k);
+                const uint32_t p1 = (uint32_t)__builtin_amdgcn_readlane((int)vp1, (int)k), p2 = (uint32_t)__builtin_amdgcn_readlane((int)vp2, (int)k);
+                const uint32_t hb = p1 & 0xFFu, tb = (p1 >> 8) & 0xFFu, token = (p1 >> 16) & 0xFFu, off = p2 & 0xFFFFu;
+                if (hb) {
+                    const uint32_t hi = lane < hb - 1 ? lane : hb - 1, ti = lane < tb - 1 ? lane : tb - 1;
+                    o[hi] = (uint8_t)(hi == 0 ? token : hi < hb - 1 ? 255u : p1 >> 24);
+                    o += hb;
+                    wave_copy_disjoint(o, lp, lit);
+                    o += lit;
+                    o[ti] = (uint8_t)(ti == 0 ? off : ti == 1 ? off >> 8 : ti < tb - 1 ? 255u : p2 >> 16);
+                    o += tb;
+                } else {
+                    const uint32_t mcode = adv - lit - MINMATCH;
+                    if (lane == 0) *o = (uint8_t)token;
+                    o += 1;
+                    if (lit >= 15) { emit_len_ext(o, lit - 15); o += len_ext_bytes(lit); }
+                    wave_copy_disjoint(o, lp, lit);
+                    o += lit;
+                    if (lane == 0) { o[0] = (uint8_t)off; o[1] = (uint8_t)(off >> 8); }
+                    o += 2;
+                    if (mcode >= 15) { emit_len_ext(o, mcode - 15); o += len_ext_bytes(mcode); }
+                }
+                lp += adv;
+            }
+        }
+#else
         for (uint32_t r = 0; r < ci.nrec; r++) {
             if (ent && (r % IX_STRIDE) == 0 && lane == 0) {
                 uint32_t ns = ci.nrec - r < IX_STRIDE ? ci.nrec - r : IX_STRIDE;
@@ -1136,6 +1190,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_emit_gather(const uint8_t
             }
             lp += lit + mlen;
         }
+#endif
         o_off = (uint64_t)(o - dst); lp_off = (uint64_t)(lp - src);
     } else
     for (uint32_t r0 = 0; r0 < ci.nrec; r0 += WAVE) {
