@@ -30,6 +30,7 @@ module Codec.Compression.LZ4.Conduit.Batched
   , compressBatched
   , decompressBatched
   , defaultBatchBytes
+  , appendBlockList
   ) where
 
 import           Control.Concurrent (forkIO)
@@ -47,7 +48,7 @@ import           Data.IORef (newIORef, readIORef, writeIORef)
 import           Data.Word (Word32)
 import           Foreign.C.String (CString)
 import           Foreign.C.Types (CChar, CSize (..), CUInt (..))
-import           Foreign.Marshal.Alloc (alloca, free, mallocBytes)
+import           Foreign.Marshal.Alloc (alloca, allocaBytes, free, mallocBytes)
 import           Foreign.Marshal.Utils (copyBytes, new)
 import           Foreign.Ptr (FunPtr, Ptr, freeHaskellFunPtr, nullPtr, plusPtr)
 import           Foreign.Storable (peek)
@@ -74,6 +75,9 @@ foreign import ccall safe   "lz4f_mi355x_host_free"        c_hostFree :: Ptr CCh
 type YieldFn = Ptr () -> Ptr CChar -> CSize -> IO ()
 foreign import ccall safe   "lz4f_mi355x_decompressFrameTo" c_decompressFrameTo :: FunPtr YieldFn -> Ptr () -> Ptr CChar -> CSize -> Ptr CSize -> IO CSize
 foreign import ccall "wrapper" mkYieldFn :: YieldFn -> IO (FunPtr YieldFn)
+-- the block list of a finished frame (include/lz4f_mi355x.h: host work only, no GPU)
+foreign import ccall unsafe "lz4f_mi355x_blockListSize"     c_blockListSize :: Ptr CChar -> CSize -> IO CSize
+foreign import ccall unsafe "lz4f_mi355x_appendBlockList"   c_appendBlockList :: Ptr CChar -> CSize -> CSize -> IO CSize
 
 
 -- | Same message format as the reference's @handleLz4Error@ (@Conduit.hsc:149-160@).
@@ -85,6 +89,20 @@ checkLz4 act = do
     name <- unsafePackCString =<< c_getErrorName r
     throwString ("lz4frame error: " ++ show name)
   return r
+
+
+-- | A finished LZ4 frame (this library's or any other encoder's, held whole) followed by its block list as a skippable
+-- frame: every LZ4 reader skips it, @lz4f_mi355x_dev_decompressFrame@ finds the blocks through it instead of walking the
+-- size words.  Throws the library's error (@ERROR_frameSize_wrong@ when the bytes are not exactly one frame).
+appendBlockList :: ByteString -> IO ByteString
+appendBlockList frame = unsafeUseAsCStringLen frame $ \(p, n) -> do
+  extra <- checkLz4 (c_blockListSize p (fromIntegral n))
+  if extra == 0 then return frame else do
+    let total = n + fromIntegral extra
+    allocaBytes total $ \buf -> do                      -- (released also when the call below throws)
+      copyBytes buf p n
+      r <- checkLz4 (c_appendBlockList buf (fromIntegral n) (fromIntegral total))
+      packCStringLen (buf, fromIntegral r)
 
 
 lz4fVersion :: CUInt
