@@ -34,6 +34,7 @@ class Engine:
         _chk(self.L, self.L.lz4f_mi355x_engine_create(ctypes.byref(h), device, ctypes.c_void_p(self.stream.cuda_stream), 1))
         self.h = h
         self._res = torch.zeros(32, dtype=torch.uint8, device="cuda:%d" % device)
+        self._res_host = torch.zeros(32, dtype=torch.uint8).pin_memory()      # the result record comes back by DMA into page-locked memory: one wait, no staging
 
     def close(self):
         if self.h:
@@ -62,8 +63,10 @@ class Engine:
 
     # -- helpers
     def _result(self) -> Result:
-        r = Result.from_buffer_copy(self._res.cpu().numpy().tobytes())
-        return r
+        with torch.cuda.stream(self.stream):
+            self._res_host.copy_(self._res, non_blocking=True)
+        self.stream.synchronize()
+        return Result.from_buffer_copy(self._res_host.numpy().tobytes())
 
     def frame_bound(self, n: int, prefs: Preferences) -> int:
         return _chk(self.L, self.L.lz4f_mi355x_compressFrameBound(n, ctypes.byref(prefs)))
@@ -106,8 +109,7 @@ class Engine:
         _chk(self.L, self.L.lz4f_mi355x_dev_decompressFrame(self.h, dst.data_ptr(), dst.numel(), frame.data_ptr(), frame_len, self._res.data_ptr()))
 
     def result(self) -> Result:
-        self.stream.synchronize()
-        r = self._result()
+        r = self._result()                                   # (waits for the stream: everything enqueued so far, then the record's copy)
         if r.status != 0:
             raise DeviceCodecError("%s at block %d" % (self.L.LZ4F_getErrorName((1 << 64) - r.status).decode(), r.first_bad_block))
         return r
