@@ -803,13 +803,11 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
 // Three launches: per block on a wave (chunks in the lanes, carries and offsets by prefix sums), the scan over the blocks on
 // one workgroup, the per-chunk fix-up on a thread per chunk.
 
-template <int WAVES_PER_WG>
-__global__ __launch_bounds__(64 * WAVES_PER_WG) void k_layout_blocks(EncGeom g, ChunkInfo* __restrict__ info, BlockOut* __restrict__ table,
-                                                                     uint32_t* __restrict__ blk_bytes)
+// (the three steps as device functions: a call of a few blocks - the streaming API's one block per call - runs them in ONE launch,
+// k_layout_small below; each of these launches costs ~5 us of an otherwise idle GPU there)
+__device__ __forceinline__ void layout_block(const EncGeom& g, ChunkInfo* __restrict__ info, BlockOut* __restrict__ table, uint32_t* __restrict__ blk_bytes, uint32_t b)
 {
     const uint32_t lane = lane_id();
-    const uint32_t b = uni(blockIdx.x * WAVES_PER_WG + (threadIdx.x >> 6));
-    if (b >= g.n_blocks) return;
     const uint64_t bstart = g.first_off + (uint64_t)b * g.block_size;
     const uint32_t blen = (uint32_t)((bstart + g.block_size < g.src_size) ? g.block_size : g.src_size - bstart);
     ChunkInfo* ci = info + (uint64_t)b * g.chunks_per_block;
@@ -847,13 +845,20 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_layout_blocks(EncGeom g, 
         blk_bytes[b] = 4 + (raw ? blen : total) + 4 * g.block_checksum;
     }
 }
-
-// the scan over the blocks, header, EndMark, result record (one workgroup)
-__global__ __launch_bounds__(1024) void k_layout_scan(EncGeom g, BlockOut* __restrict__ table, const uint32_t* __restrict__ blk_bytes,
-                                                      uint8_t* __restrict__ dst, uint64_t dst_cap, ResultRec* __restrict__ res, const uint64_t* __restrict__ recs)
+template <int WAVES_PER_WG>
+__global__ __launch_bounds__(64 * WAVES_PER_WG) void k_layout_blocks(EncGeom g, ChunkInfo* __restrict__ info, BlockOut* __restrict__ table,
+                                                                     uint32_t* __restrict__ blk_bytes)
 {
-    __shared__ uint64_t s_part[1024];
-    __shared__ uint64_t s_carry;
+    const uint32_t b = uni(blockIdx.x * WAVES_PER_WG + (threadIdx.x >> 6));
+    if (b >= g.n_blocks) return;
+    layout_block(g, info, table, blk_bytes, b);
+}
+
+// the scan over the blocks, header, EndMark, result record (one workgroup of 1024)
+__device__ __forceinline__ void layout_scan(const EncGeom& g, BlockOut* __restrict__ table, const uint32_t* __restrict__ blk_bytes,
+                                            uint8_t* __restrict__ dst, uint64_t dst_cap, ResultRec* __restrict__ res, const uint64_t* __restrict__ recs,
+                                            uint64_t* s_part, uint64_t& s_carry)
+{
     const uint32_t t = threadIdx.x;
     if (t == 0) s_carry = g.header_size;
     __syncthreads();
@@ -883,14 +888,22 @@ __global__ __launch_bounds__(1024) void k_layout_scan(EncGeom g, BlockOut* __res
         res->size = fits ? frame_size : 0; res->consumed = g.src_size - g.first_off;
         res->status = fits ? ST_OK : ST_DSTSMALL; res->n_blocks = g.n_blocks; res->first_bad_block = 0xFFFFFFFFu; res->flags = g.header[4] | ((g.n_chunks && rec_ctl(recs)[1]) ? ENC_POOL_SHORT : 0u);
     }
+    // (the pool's bump pointer and its count of tiles turned away: read, and left at zero for the next call's pass E1 - the host zeroes them
+    // only when the workspace is new)
+    if (t == 0 && g.n_chunks) { rec_ctl(recs)[0] = 0ull; rec_ctl(recs)[1] = 0ull; }
+}
+__global__ __launch_bounds__(1024) void k_layout_scan(EncGeom g, BlockOut* __restrict__ table, const uint32_t* __restrict__ blk_bytes,
+                                                      uint8_t* __restrict__ dst, uint64_t dst_cap, ResultRec* __restrict__ res, const uint64_t* __restrict__ recs)
+{
+    __shared__ uint64_t s_part[1024];
+    __shared__ uint64_t s_carry;
+    layout_scan(g, table, blk_bytes, dst, dst_cap, res, recs, s_part, s_carry);
 }
 
 // a thread per chunk: absolute offsets; the first chunk of a block writes the block's size word
-__global__ __launch_bounds__(256) void k_layout_chunks(EncGeom g, ChunkInfo* __restrict__ info, const BlockOut* __restrict__ table,
-                                                       uint8_t* __restrict__ dst, const ResultRec* __restrict__ res)
+__device__ __forceinline__ void layout_chunk(const EncGeom& g, ChunkInfo* __restrict__ info, const BlockOut* __restrict__ table,
+                                             uint8_t* __restrict__ dst, const ResultRec* res, uint32_t chunk)
 {
-    const uint32_t chunk = blockIdx.x * 256 + threadIdx.x;
-    if (chunk >= g.n_chunks) return;
     if (res->status != ST_OK) { info[chunk].flags |= 4u; return; }               // does not fit: pass E2 does nothing
     const uint32_t b = chunk / g.chunks_per_block, c = chunk % g.chunks_per_block;
     const BlockOut e = table[b];
@@ -898,6 +911,27 @@ __global__ __launch_bounds__(256) void k_layout_chunks(EncGeom g, ChunkInfo* __r
     if (c == 0) { const uint32_t w = e.word; uint8_t* q = dst + e.src_off - 4; q[0] = (uint8_t)w; q[1] = (uint8_t)(w >> 8); q[2] = (uint8_t)(w >> 16); q[3] = (uint8_t)(w >> 24); }
     if (c >= nch) return;
     info[chunk].out_off = (e.word >> 31) ? e.src_off + (uint64_t)c * g.chunk_size : e.src_off + info[chunk].out_off;
+}
+__global__ __launch_bounds__(256) void k_layout_chunks(EncGeom g, ChunkInfo* __restrict__ info, const BlockOut* __restrict__ table,
+                                                       uint8_t* __restrict__ dst, const ResultRec* __restrict__ res)
+{
+    const uint32_t chunk = blockIdx.x * 256 + threadIdx.x;
+    if (chunk >= g.n_chunks) return;
+    layout_chunk(g, info, table, dst, res, chunk);
+}
+// the three in one launch, for calls of a few blocks (<= LAYOUT_SMALL_BLOCKS blocks): one workgroup, a wave per block, then the scan, then a
+// thread per chunk - what one step leaves in memory for the next is the workgroup's own, behind a barrier
+constexpr uint32_t LAYOUT_SMALL_BLOCKS = 64, LAYOUT_SMALL_CHUNKS = 4096;
+__global__ __launch_bounds__(1024) void k_layout_small(EncGeom g, ChunkInfo* info, BlockOut* table, uint32_t* blk_bytes, uint8_t* __restrict__ dst, uint64_t dst_cap,
+                                                       ResultRec* res, const uint64_t* __restrict__ recs)
+{
+    __shared__ uint64_t s_part[1024];
+    __shared__ uint64_t s_carry;
+    for (uint32_t b = uni(threadIdx.x >> 6); b < g.n_blocks; b += 16) layout_block(g, info, table, blk_bytes, b);
+    __threadfence_block(); __syncthreads();
+    layout_scan(g, table, blk_bytes, dst, dst_cap, res, recs, s_part, s_carry);
+    __threadfence_block(); __syncthreads();
+    for (uint32_t chunk = threadIdx.x; chunk < g.n_chunks; chunk += 1024) layout_chunk(g, info, table, dst, res, chunk);
 }
 
 // ------------------------------- sequence index (optional) -------------------------------------

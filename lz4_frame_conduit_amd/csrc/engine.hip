@@ -289,7 +289,10 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
 #ifdef E1_DEBUG
             (void)hipMemsetAsync((uint8_t*)e1_scratch.p + (size_t)n_wg * 2 * E1_NSLICE * E1_REC_PER_SLICE * 8, 0, 2048, st);
 #endif
-            HIP_TRY(hipMemsetAsync(recs.p, 0, 64, st));                 // the pool's bump pointer and its count of tiles turned away
+            // (the pool's bump pointer and its count of tiles turned away: every call's scan leaves them at zero for the next; zeroed here when the
+            // workspace is new, or when a call before this one may not have got as far as its scan)
+            if (recs_ctl_clean != recs.p) { HIP_TRY(hipMemsetAsync(recs.p, 0, 64, st)); }
+            recs_ctl_clean = nullptr;
             hipLaunchKernelGGL(k_find_matches, dim3(n_wg), dim3(64 * E1_WAVES), 0, st, j.d_src, g, (ChunkInfo*)info.p, (uint64_t*)recs.p, (uint64_t*)e1_scratch.p);
             if (sw.e1_sync) (void)hipStreamSynchronize(st);
 #ifdef E1_DEBUG
@@ -303,9 +306,14 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     }
     tick(1, false);
     {
+        if (g.n_blocks <= LAYOUT_SMALL_BLOCKS && g.n_chunks <= LAYOUT_SMALL_CHUNKS)       // (a few blocks - the streaming API's one per call: one launch instead of three)
+            hipLaunchKernelGGL(k_layout_small, dim3(1), dim3(1024), 0, st, g, (ChunkInfo*)info.p, (BlockOut*)d_table, (uint32_t*)blk_bytes.p, d_dst, dst_cap, (ResultRec*)d_res, (const uint64_t*)recs.p);
+        else {
         if (g.n_blocks) hipLaunchKernelGGL((k_layout_blocks<W>), dim3((g.n_blocks + W - 1) / W), dim3(64 * W), 0, st, g, (ChunkInfo*)info.p, (BlockOut*)d_table, (uint32_t*)blk_bytes.p);
         hipLaunchKernelGGL(k_layout_scan, dim3(1), dim3(1024), 0, st, g, (BlockOut*)d_table, (const uint32_t*)blk_bytes.p, d_dst, dst_cap, (ResultRec*)d_res, (const uint64_t*)recs.p);
         if (g.n_chunks) hipLaunchKernelGGL(k_layout_chunks, dim3((g.n_chunks + 255) / 256), dim3(256), 0, st, g, (ChunkInfo*)info.p, (const BlockOut*)d_table, d_dst, (const ResultRec*)d_res);
+        }
+        if (g.n_chunks) recs_ctl_clean = recs.p;                                  // (the scan is enqueued: it leaves the pool's control words at zero)
         if (d_index) {                                                            // sequence index for the indexed decoder
             if (g.n_blocks) hipLaunchKernelGGL((k_index_blocks<W>), dim3((g.n_blocks + W - 1) / W), dim3(64 * W), 0, st, g, (const ChunkInfo*)info.p, (const BlockOut*)d_table, (const ResultRec*)d_res, d_index, (uint64_t)index_cap);
             hipLaunchKernelGGL(k_build_index, dim3(1), dim3(1024), 0, st, g, (const ChunkInfo*)info.p, (const BlockOut*)d_table, (const ResultRec*)d_res, d_index, (uint64_t)index_cap, 1u);

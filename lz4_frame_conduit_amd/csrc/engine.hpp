@@ -72,6 +72,7 @@ struct lz4f_mi355x_engine {
         int chain_gate; char decode_mode; unsigned e1_run, e1_solo, seed, dblk_lds, recs_per_tile; unsigned long long wait_ticks;
         void read();
     } sw;
+    void*  recs_ctl_clean = nullptr;                       // == recs.p while the record pool's control words are known to be zero (or about to be: the last call's scan)
     size_t ix_seq_cap = 0;                                 // indexed decode: descriptor workspace, in sequences (grow-only)
     bool  timing = false;
     void* ev[24] = {nullptr};      // hipEvent_t pairs (begin,end) per timing slot
