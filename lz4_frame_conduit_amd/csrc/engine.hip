@@ -356,6 +356,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
     if (bad.ensure(64)) return make_err(LZ4F_ERROR_allocation_failed);
     BlockOut* tbl;
     uint32_t n_max;
+    bool bad_set = false;                                            // the finishing kernels' verdict words are initialised by a kernel already launched
     uint32_t plan = 0;                                               // LZ4F_MI355X_PATH_*: reported in result.flags
     for (int i = 4; i < 10; i++) ev_used[i] = false;
     ev_used[11] = false;
@@ -368,9 +369,15 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         tbl = (BlockOut*)table.p;
         if (!j.table_in_place)
             HIP_TRY(hipMemcpyAsync(tbl, j.d_table, (size_t)n_max * sizeof(BlockOut), hipMemcpyDeviceToDevice, st));
+        if (n_max <= 256) {                                          // (a few blocks - the streaming API's one per call: one launch for the record, the verdict words and the table check)
+            hipLaunchKernelGGL(k_begin_table_small, dim3(1), dim3(256), 0, st, (const BlockOut*)tbl, n_max, (uint64_t)j.frame_cap, (uint64_t)j.dst_cap,
+                               j.block_size, j.block_checksum ? 1u : 0u, j.linked ? 1u : 0u, (ResultRec*)d_res, (uint32_t*)bad.p);
+            bad_set = true;
+        } else {
         hipLaunchKernelGGL(k_init_result, dim3(1), dim3(64), 0, st, (ResultRec*)d_res, n_max, 0u);
         if (n_max) hipLaunchKernelGGL(k_check_table, dim3(std::min<uint32_t>((n_max + 255) / 256, 1024u)), dim3(256), 0, st, (const BlockOut*)tbl, n_max, (uint64_t)j.frame_cap, (uint64_t)j.dst_cap,
                                       j.block_size, j.block_checksum ? 1u : 0u, j.linked ? 1u : 0u, (ResultRec*)d_res);
+        }
         plan |= LZ4F_MI355X_PATH_TABLE_GIVEN;
     } else {
         n_max = j.max_blocks;
@@ -437,8 +444,10 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         hipLaunchKernelGGL(k_walk_frame, dim3(1), dim3(64), 0, st, j.d_frame, j.frame_cap, j.dst_cap, tbl, n_max, (ResultRec*)d_res, walked);
         tick(4, true);
     }
-    HIP_TRY(hipMemsetAsync(bad.p, 0xFF, 8, st));                     // [0] block-checksum verdict, [1] first failed block
-    HIP_TRY(hipMemsetAsync((uint8_t*)bad.p + 8, 0, 24, st));        // [2] "something has to move", [4..5] sum of sizes (k_finish_check)
+    if (!bad_set) {
+        HIP_TRY(hipMemsetAsync(bad.p, 0xFF, 8, st));                 // [0] block-checksum verdict, [1] first failed block
+        HIP_TRY(hipMemsetAsync((uint8_t*)bad.p + 8, 0, 24, st));    // [2] "something has to move", [4..5] sum of sizes (k_finish_check)
+    }
     constexpr int W = 4;
     const uint32_t grid = j.linked ? 1u : (n_max + W - 1) / W;
     const uint32_t* ix_flags = nullptr;                              // the indexed kernels' "gave up" word, if they were launched
@@ -730,9 +739,10 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
     }
     if (aux_pending) { HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0)); aux_pending = false; }
     tick(7, false);
-    if (n_max) hipLaunchKernelGGL(k_finish_check, dim3((n_max + 255) / 256), dim3(256), 0, st, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, (uint32_t*)bad.p);
+    const bool check_here = n_max <= 64;                              // (the finishing wave looks at a few blocks itself: a launch less)
+    if (n_max && !check_here) hipLaunchKernelGGL(k_finish_check, dim3((n_max + 255) / 256), dim3(256), 0, st, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, (uint32_t*)bad.p);
     hipLaunchKernelGGL(k_finish_decode, dim3(1), dim3(64), 0, st, j.d_dst, tbl, (ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size,
-                       (const uint32_t*)bad.p, j.block_checksum ? 1u : 0u, plan, ix_flags);
+                       (const uint32_t*)bad.p, j.block_checksum ? 1u : 0u, plan, ix_flags, check_here ? 1u : 0u);
     if (j.content_checksum && !j.d_table && !j.table_in_place && !sw.no_content_check)      // (a whole frame was walked: res->consumed is behind its checksum word)
         hipLaunchKernelGGL(k_xxh32_content, dim3(1), dim3(64), 0, st, (const uint8_t*)j.d_dst, 0ull, (uint8_t*)j.d_frame, (ResultRec*)d_res, 1u);
     tick(7, true);
@@ -916,8 +926,10 @@ static size_t status_to_err(uint32_t st)
 }
 
 size_t lz4f_mi355x_engine::slab_decode(const uint8_t* frame_part, size_t part_len, const std::vector<lz4f_mi355x_block>& entries,
-                                       const ParsedHeader& ph, const uint8_t* hist, size_t hist_len, bool src_pinned, size_t* got)
-{
+                                       const ParsedHeader& ph, const uint8_t* hist, size_t hist_len, bool src_pinned, size_t* got,
+                                       uint8_t* fetch_to, size_t fetch_room)
+{   // fetch_to (one block of at most 256 KiB - the streaming API's call): the output comes back with the result record, before the ONE
+    // synchronisation of the call - a block's worth is copied whatever the block decodes to, and what it did decode to goes to fetch_to
     HIP_TRY(hipSetDevice(device));
     hipStream_t st = (hipStream_t)stream;
     const bool linked = ph.info.blockMode == LZ4F_blockLinked;
@@ -949,10 +961,17 @@ size_t lz4f_mi355x_engine::slab_decode(const uint8_t* frame_part, size_t part_le
     size_t r = launch_decompress(j, (lz4f_mi355x_result*)res.p);
     if (is_err(r)) return r;
     ResultRec* hr = (ResultRec*)(hp + at_tab + tbytes + hist_len + 8 - ((at_tab + tbytes + hist_len) & 7) + 8);
+    const bool with_out = fetch_to && nb == 1 && ph.max_block <= (256u << 10) && !h_out.ensure(ph.max_block + 64);
+    if (with_out) HIP_TRY(hipMemcpyAsync(h_out.p, (const uint8_t*)d_out.p + hist_len, ph.max_block, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(hr, res.p, sizeof(ResultRec), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     if (hr->status != ST_OK) { set_last_error("device decode status %u at block %u", hr->status, hr->first_bad_block); return status_to_err(hr->status); }
     *got = hr->size;
+    if (fetch_to) {
+        if (hr->size > fetch_room) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
+        if (with_out) memcpy(fetch_to, h_out.p, hr->size);
+        else { const size_t r2 = slab_fetch(fetch_to, hr->size, hist_len, false); if (is_err(r2)) return r2; }
+    }
     return 0;
 }
 
@@ -962,10 +981,7 @@ size_t lz4f_mi355x_engine::run_decode_slab(const uint8_t* frame_part, size_t par
     const bool linked = ph.info.blockMode == LZ4F_blockLinked;
     if (!linked) hist_len = 0;
     size_t n = 0;
-    size_t r = slab_decode(frame_part, part_len, entries, ph, hist, hist_len, false, &n);
-    if (is_err(r)) return r;
-    if (n > dst_room) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
-    r = slab_fetch(dst, n, hist_len, false);
+    size_t r = slab_decode(frame_part, part_len, entries, ph, hist, hist_len, false, &n, dst, dst_room);
     if (is_err(r)) return r;
     *got = n;
     return 0;

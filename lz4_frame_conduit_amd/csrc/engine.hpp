@@ -125,7 +125,7 @@ struct lz4f_mi355x_engine {
     size_t compress_block_pinned(const uint8_t* pin_src, size_t hist_len, size_t n, uint32_t block_size, bool linked, bool block_checksum,
                                  uint8_t* pin_dst, size_t dst_cap, void* pin_res, size_t* size);
     size_t slab_decode(const uint8_t* frame_part, size_t part_len, const std::vector<lz4f_mi355x_block>& entries, const lz4f::ParsedHeader& ph,
-                       const uint8_t* hist, size_t hist_len, bool src_pinned, size_t* got);
+                       const uint8_t* hist, size_t hist_len, bool src_pinned, size_t* got, uint8_t* fetch_to = nullptr, size_t fetch_room = 0);
     // Decode one compressed block payload (host; followed by its 4-byte checksum when bck) with `hist_len`
     // bytes of history (host, linked frames).  The checksum is verified and the block decoded on the GPU;
     // the decoded bytes land in dst (host).

@@ -785,8 +785,8 @@ __global__ void k_init_result(ResultRec* res, uint32_t n_blocks, uint32_t flags)
 // buffer, and the entries in order without overlap on either side - the blocks are decoded concurrently, so two entries that share output
 // bytes would be a race, and entries that share frame bytes are not a walk of any frame.  A table that fails gets ERROR_GENERIC and
 // first_bad_block; nothing is decoded (every decode kernel returns at once on a result that is not OK).
-__global__ __launch_bounds__(256) void k_check_table(const BlockOut* __restrict__ table, uint32_t n, uint64_t frame_cap, uint64_t dst_cap, uint32_t block_size,
-                                                     uint32_t bck, uint32_t linked, ResultRec* __restrict__ res)
+__device__ __forceinline__ void check_table_entries(const BlockOut* __restrict__ table, uint32_t n, uint64_t frame_cap, uint64_t dst_cap, uint32_t block_size,
+                                                    uint32_t bck, uint32_t linked, ResultRec* res)
 {
     for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         const BlockOut e = table[i];
@@ -800,6 +800,22 @@ __global__ __launch_bounds__(256) void k_check_table(const BlockOut* __restrict_
         }
         if (bad) { atomicMin(&res->first_bad_block, i); atomicMax(&res->status, (uint32_t)ST_GENERIC); }
     }
+}
+__global__ __launch_bounds__(256) void k_check_table(const BlockOut* __restrict__ table, uint32_t n, uint64_t frame_cap, uint64_t dst_cap, uint32_t block_size,
+                                                     uint32_t bck, uint32_t linked, ResultRec* __restrict__ res)
+{
+    check_table_entries(table, n, frame_cap, dst_cap, block_size, bck, linked, res);
+}
+// The same for a table of a few blocks (the streaming API: one block per call) in ONE launch with what else a decode call begins with: the
+// result record's initial state and the verdict words of the finishing kernels (`w`: [0] block-checksum verdict, [1] first failed block,
+// [2] "something has to move", [4..5] sum of the sizes).  One workgroup: the record is set before anybody checks against it.
+__global__ __launch_bounds__(256) void k_begin_table_small(const BlockOut* __restrict__ table, uint32_t n, uint64_t frame_cap, uint64_t dst_cap, uint32_t block_size,
+                                                           uint32_t bck, uint32_t linked, ResultRec* res, uint32_t* __restrict__ w)
+{
+    if (threadIdx.x == 0) { res->size = 0; res->consumed = 0; res->status = ST_OK; res->n_blocks = n; res->first_bad_block = 0xFFFFFFFFu; res->flags = 0u; }
+    if (threadIdx.x < 8) w[threadIdx.x] = threadIdx.x < 2 ? 0xFFFFFFFFu : 0u;
+    __threadfence_block(); __syncthreads();
+    check_table_entries(table, n, frame_cap, dst_cap, block_size, bck, linked, res);
 }
 __global__ void k_set_block(BlockOut* t, BlockOut e) { if (threadIdx.x == 0 && blockIdx.x == 0) *t = e; }
 
@@ -921,16 +937,30 @@ __global__ __launch_bounds__(256) void k_finish_check(const BlockOut* __restrict
 
 __global__ __launch_bounds__(64) void k_finish_decode(uint8_t* dst, BlockOut* __restrict__ table, ResultRec* res, uint32_t n_max,
                                                       uint32_t linked, uint32_t block_size, const uint32_t* __restrict__ bad_ck, uint32_t with_ck,
-                                                      uint32_t plan = 0, const uint32_t* __restrict__ ix_flags = nullptr)
-{
+                                                      uint32_t plan = 0, const uint32_t* __restrict__ ix_flags = nullptr, uint32_t check_here = 0)
+{   // check_here (n_max <= 64): what k_finish_check leaves in bad_ck[1], [2], [4..5] is worked out by this wave itself - a launch less for calls of a few blocks
     // which way the call went (lz4f_mi355x.h: LZ4F_MI355X_PATH_*): what the host launched, and whether the indexed kernels gave up
     if (lane_id() == 0) res->flags = (res->flags & 0xFFFu) | (plan << 12) | ((ix_flags && *ix_flags) ? (LZ4F_MI355X_PATH_INDEX_DROPPED << 12) : 0u);
     if (res->status != ST_OK) return;
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
     uint32_t n_scan = n;
     const uint32_t lane = lane_id();
+    uint32_t w1 = 0xFFFFFFFFu, w2 = 0u; uint64_t w45 = 0;
+    if (check_here) {                                                  // (k_finish_check's rules, a block per lane)
+        const bool in = lane < n;
+        const uint32_t sz = in ? table[lane].dst_size : 0u;
+        const uint64_t at = in ? table[lane].dst_off : 0ull;
+        const bool bad = in && (int32_t)sz < 0;
+        const uint64_t bm = __ballot(bad);
+        if (bm) w1 = (uint32_t)__builtin_ctzll(bm);
+        w2 = __ballot(in && !linked && (at != (uint64_t)lane * block_size || (lane + 1 < n && sz != block_size))) ? 1u : 0u;
+        uint64_t sum = bad ? 0u : sz;
+#pragma unroll
+        for (int sft = 1; sft < 64; sft <<= 1) sum += __shfl_xor(sum, sft);
+        w45 = sum;
+    } else { w1 = bad_ck[1]; w2 = bad_ck[2]; w45 = *(const uint64_t*)(bad_ck + 4); }
     // first failed block (k_finish_check)
-    const uint32_t first_bad = bad_ck[1] < n ? bad_ck[1] : 0xFFFFFFFFu;
+    const uint32_t first_bad = w1 < n ? w1 : 0xFFFFFFFFu;
     const uint32_t bad_kind = first_bad != 0xFFFFFFFFu ? table[first_bad].dst_size : 0u;
     const uint32_t ck = with_ck ? bad_ck[0] : 0xFFFFFFFFu;
     if (ck != 0xFFFFFFFFu && ck <= first_bad) {
@@ -943,8 +973,8 @@ __global__ __launch_bounds__(64) void k_finish_decode(uint8_t* dst, BlockOut* __
     }
     // usual case, checked 64 blocks per step: every block already sits where its predecessors end (all blocks but
     // the last decoded to full size), so nothing has to move and the total is a sum
-    uint64_t out = *(const uint64_t*)(bad_ck + 4);
-    bool in_place = bad_ck[2] == 0;
+    uint64_t out = w45;
+    bool in_place = w2 == 0;
     if (!in_place) { out = 0; in_place = true; }                       // (k_finish_check's rule is stricter than needed: look properly)
     else n_scan = 0;
     for (uint32_t b0 = 0; b0 < n_scan; b0 += WAVE) {
