@@ -362,12 +362,15 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
     ev_used[11] = false;
     if (aux_pending) { HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0)); aux_pending = false; }      // (a call that left early: its forked work first)
     tick(11, false);
-    if (j.d_table || j.table_in_place) {
-        // caller-supplied table: work on a copy (decode overwrites dst_size)
+    if (j.d_table || j.table_in_place || j.table_direct) {
+        // caller-supplied table: work on a copy (decode overwrites dst_size); table_direct: the engine's own staging copy, used where it lies
         n_max = j.n_blocks;
-        if (table.ensure((size_t)(n_max + 1) * sizeof(BlockOut))) return make_err(LZ4F_ERROR_allocation_failed);
-        tbl = (BlockOut*)table.p;
-        if (!j.table_in_place)
+        if (j.table_direct) tbl = (BlockOut*)j.table_direct;
+        else {
+            if (table.ensure((size_t)(n_max + 1) * sizeof(BlockOut))) return make_err(LZ4F_ERROR_allocation_failed);
+            tbl = (BlockOut*)table.p;
+        }
+        if (!j.table_in_place && !j.table_direct)
             HIP_TRY(hipMemcpyAsync(tbl, j.d_table, (size_t)n_max * sizeof(BlockOut), hipMemcpyDeviceToDevice, st));
         if (n_max <= 256) {                                          // (a few blocks - the streaming API's one per call: one launch for the record, the verdict words and the table check)
             hipLaunchKernelGGL(k_begin_table_small, dim3(1), dim3(256), 0, st, (const BlockOut*)tbl, n_max, (uint64_t)j.frame_cap, (uint64_t)j.dst_cap,
@@ -570,7 +573,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             }
         }
         // (linked frames: only with a table that has every block's output position - the compressor's, or the one just made)
-        if (mode == 'f' && d_index && index_size >= sizeof(IxHeader) && (!j.linked || self_indexed || ((j.d_table || j.table_in_place) && j.hist0 <= 65536)) &&
+        if (mode == 'f' && d_index && index_size >= sizeof(IxHeader) && (!j.linked || self_indexed || ((j.d_table || j.table_in_place || j.table_direct) && j.hist0 <= 65536)) &&
             !sw.no_index) {
             // Descriptors from the compressor's sequence index: a lane per entry parses, a lane per sequence resolves direct
             // matches, a workgroup per block copies.
@@ -698,7 +701,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             // set the flag and are decoded by the generic kernel launched right behind (it returns at once otherwise)
             // (one block of a linked frame - what the streaming functions hand over per call: the window kernel is built for whole frames
             // and takes 180-210 us for a single 64 KiB block; the fused workgroup takes it directly)
-            const bool windowed = j.linked && j.dst_cap < 0xFFF00000ull && !sw.no_window && !(n_max == 1 && (j.d_table || j.table_in_place));
+            const bool windowed = j.linked && j.dst_cap < 0xFFF00000ull && !sw.no_window && !(n_max == 1 && (j.d_table || j.table_in_place || j.table_direct));
             const uint32_t* only_if = indexed ? (const uint32_t*)seqcnt.p : nullptr;      // behind the indexed kernels the generic ones only run if they gave up
             if (windowed) {
                 plan |= LZ4F_MI355X_PATH_WINDOW;
@@ -743,7 +746,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
     if (n_max && !check_here) hipLaunchKernelGGL(k_finish_check, dim3((n_max + 255) / 256), dim3(256), 0, st, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, (uint32_t*)bad.p);
     hipLaunchKernelGGL(k_finish_decode, dim3(1), dim3(64), 0, st, j.d_dst, tbl, (ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size,
                        (const uint32_t*)bad.p, j.block_checksum ? 1u : 0u, plan, ix_flags, check_here ? 1u : 0u);
-    if (j.content_checksum && !j.d_table && !j.table_in_place && !sw.no_content_check)      // (a whole frame was walked: res->consumed is behind its checksum word)
+    if (j.content_checksum && !j.d_table && !j.table_in_place && !j.table_direct && !sw.no_content_check)      // (a whole frame was walked: res->consumed is behind its checksum word)
         hipLaunchKernelGGL(k_xxh32_content, dim3(1), dim3(64), 0, st, (const uint8_t*)j.d_dst, 0ull, (uint8_t*)j.d_frame, (ResultRec*)d_res, 1u);
     tick(7, true);
     tick(11, true);
@@ -939,6 +942,34 @@ size_t lz4f_mi355x_engine::slab_decode(const uint8_t* frame_part, size_t part_le
     // compacted when some are short (frames written with LZ4F_flush); only what is actually produced must fit the caller's buffer
     const size_t out_room = nb * ph.max_block;
     const size_t tbytes = nb * sizeof(BlockOut);
+    // One block of at most 256 KiB out of pageable memory (the streaming API's call): table, payload and history go up in ONE copy, laid out
+    // [table | payload | history] in front of the output - three copies of a few KiB each cost more in launches than in bytes
+    const bool one_up = fetch_to && nb == 1 && !src_pinned && ph.max_block <= (256u << 10);
+    const size_t up_pay = 64, up_hist = (up_pay + part_len + 63 + 64) & ~(size_t)63, up_out = (up_hist + hist_len + 63) & ~(size_t)63;      // (history right-aligned in front of the output)
+    if (one_up) {
+        if (h_in.ensure(up_out + 256) || d_out.ensure(up_out + out_room + 64) || res.ensure(sizeof(ResultRec))) return make_err(LZ4F_ERROR_allocation_failed);
+        uint8_t* hp = (uint8_t*)h_in.p;
+        memcpy(hp, entries.data(), tbytes);
+        memcpy(hp + up_pay, frame_part, part_len);
+        if (hist_len) memcpy(hp + up_out - hist_len, hist, hist_len);
+        { std::lock_guard<std::mutex> up(up_token(device)); HIP_TRY(hipMemcpyAsync(d_out.p, hp, up_out, hipMemcpyHostToDevice, st)); }
+        DecompressJob j; memset(&j, 0, sizeof(j));
+        j.d_frame = (const uint8_t*)d_out.p + up_pay; j.frame_cap = part_len; j.d_dst = (uint8_t*)d_out.p + up_out; j.dst_cap = out_room; j.hist0 = hist_len;
+        j.block_size = (uint32_t)ph.max_block; j.linked = linked; j.block_checksum = ph.info.blockChecksumFlag != 0;
+        j.table_direct = (lz4f_mi355x_block*)d_out.p; j.n_blocks = 1; j.max_blocks = 1;
+        size_t r = launch_decompress(j, (lz4f_mi355x_result*)res.p);
+        if (is_err(r)) return r;
+        ResultRec* hr = (ResultRec*)(hp + up_out + 64);
+        if (h_out.ensure(ph.max_block + 64)) return make_err(LZ4F_ERROR_allocation_failed);
+        HIP_TRY(hipMemcpyAsync(h_out.p, j.d_dst, ph.max_block, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(hr, res.p, sizeof(ResultRec), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (hr->status != ST_OK) { set_last_error("device decode status %u at block %u", hr->status, hr->first_bad_block); return status_to_err(hr->status); }
+        *got = hr->size;
+        if (hr->size > fetch_room) return make_err(LZ4F_ERROR_dstMaxSize_tooSmall);
+        memcpy(fetch_to, h_out.p, hr->size);
+        return 0;
+    }
     if (h_in.ensure((src_pinned ? 0 : part_len) + tbytes + hist_len + 128) || d_in.ensure(part_len + 64) || d_out.ensure(hist_len + out_room + 64) ||
         res.ensure(sizeof(ResultRec)) || table.ensure((nb + 1) * sizeof(BlockOut)))
         return make_err(LZ4F_ERROR_allocation_failed);

@@ -101,6 +101,7 @@ struct lz4f_mi355x_engine {
         bool content_checksum;                                   // the frame's FLG asks for one: verified behind the decode (k_xxh32_content)
         const lz4f_mi355x_block* d_table; uint32_t n_blocks;     // when d_table != null the walk is skipped
         bool table_in_place;                                     // the engine's own table already holds n_blocks entries
+        lz4f_mi355x_block* table_direct;                         // or: a table in device memory that is the engine's to overwrite (its own staging copy): used where it lies
         uint32_t max_blocks;                                     // grid bound when walking
         const uint64_t* hint_list; uint32_t hint_n;              // from the frame's trailer: where the size words should be (checked on the device)
         uint32_t ix_seqs, ix_entries;                            // what the index says it holds (header / trailer footer: sizes the workspace; checked on the device)
