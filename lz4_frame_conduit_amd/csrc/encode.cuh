@@ -1074,14 +1074,17 @@ __device__ __forceinline__ void emit_len_ext(uint8_t* p, uint32_t v /* value min
 #ifndef E2_V2
 #define E2_V2 1               // pass E2, long literal runs: the records' arithmetic in the lanes, 64 records at a time (0: the round 2 loop, all of it scalar)
 #endif
-template <int WAVES_PER_WG>
+template <int WAVES_PER_WG, bool split = false>
 __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_emit_gather(const uint8_t* __restrict__ src, EncGeom g,
                                                                    const ChunkInfo* __restrict__ info, const uint64_t* __restrict__ recs,
                                                                    uint8_t* __restrict__ dst, const BlockOut* __restrict__ table, void* __restrict__ ix)
-{
+{   // split (a call of few chunks - the streaming API's one block): the workgroup's waves share ONE chunk instead of taking one each.  Every wave
+    // walks all of the chunk's batches of 64 records for their sizes (two prefix sums), and emits its share: every nsub-th record of a batch of
+    // long literal runs, every nsub-th batch of short ones.  A 64 KiB block's emit is then a quarter as long as one wave's walk through it.
     __shared__ uint4 s_gt[WAVES_PER_WG][2][64];
     const uint32_t wave = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t chunk = uni(blockIdx.x * WAVES_PER_WG + wave);
+    const uint32_t chunk = uni(split ? blockIdx.x : blockIdx.x * WAVES_PER_WG + wave);
+    const uint32_t sub = split ? wave : 0u, nsub = split ? (uint32_t)WAVES_PER_WG : 1u;
     if (chunk >= g.n_chunks) return;
     const uint32_t blk = chunk / g.chunks_per_block, cib = chunk % g.chunks_per_block;
     const uint64_t bstart = g.first_off + (uint64_t)blk * g.block_size;
@@ -1094,6 +1097,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_emit_gather(const uint8_t
     if (ci.flags & 1u) {                                   // stored block: this chunk's slice of it
         uint8_t* o = dst + ci.out_off;
         const uint64_t n = ce_abs - cs_abs;
+        if (sub) return;
         for (uint64_t off = 0; off < n; off += 1u << 20) {
             const uint32_t m = (uint32_t)((n - off < (1u << 20)) ? n - off : (1u << 20));
             wave_copy_disjoint(o + off, src + cs_abs + off, m);
@@ -1153,6 +1157,47 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_emit_gather(const uint8_t
             const bool vbig = vhb > WAVE || vtb > WAVE;                    // (lengths of 16 KiB and more: the loop over their 255s)
             const uint32_t vp1 = (vbig ? 0u : vhb | (vtb << 8)) | (vtoken << 16) | (vlrest << 24), vp2 = voff | (vmrest << 16), vadv = vlit + vmlen;
             const uint32_t nb = ci.nrec - r0 < WAVE ? ci.nrec - r0 : WAVE;
+            if constexpr (split) {
+                // (the waves share the batch: where a record's literals come from and where its bytes go is two prefix sums over the batch, and
+                // every wave emits every nsub-th record)
+                const bool vact = rl < ci.nrec;
+                uint32_t tot_sz, tot_adv;
+                const uint32_t vso = scan(vact ? vhb + vlit + vtb : 0u, tot_sz), vsa = scan(vact ? vadv : 0u, tot_adv);
+                for (uint32_t k = sub; k < nb; k += nsub) {
+                    const uint32_t r = r0 + k;
+                    const uint32_t lit = (uint32_t)__builtin_amdgcn_readlane((int)vlit, (int)k), so = (uint32_t)__builtin_amdgcn_readlane((int)vso, (int)k);
+                    const uint32_t sa = (uint32_t)__builtin_amdgcn_readlane((int)vsa, (int)k);
+                    const uint32_t p1 = (uint32_t)__builtin_amdgcn_readlane((int)vp1, (int)k), p2 = (uint32_t)__builtin_amdgcn_readlane((int)vp2, (int)k);
+                    const uint32_t hb = p1 & 0xFFu, tb = (p1 >> 8) & 0xFFu, token = (p1 >> 16) & 0xFFu, off = p2 & 0xFFFFu;
+                    uint8_t* q = o + so;
+                    const uint8_t* ls = lp + sa;
+                    if (ent && (r % IX_STRIDE) == 0 && lane == 0) {
+                        uint32_t ns = ci.nrec - r < IX_STRIDE ? ci.nrec - r : IX_STRIDE;
+                        if (ent_last && r + IX_STRIDE >= ci.nrec) ns += 1;
+                        ent[r / IX_STRIDE] = IxEntry{(uint32_t)((uint64_t)(q - dst) - pay0), (uint32_t)((uint64_t)(ls - src) - bstart), ent_seq0 + r, ns | (blk << 8)};
+                    }
+                    if (hb) {
+                        const uint32_t hi = lane < hb - 1 ? lane : hb - 1, ti = lane < tb - 1 ? lane : tb - 1;
+                        q[hi] = (uint8_t)(hi == 0 ? token : hi < hb - 1 ? 255u : p1 >> 24);
+                        q += hb;
+                        wave_copy_disjoint(q, ls, lit);
+                        q += lit;
+                        q[ti] = (uint8_t)(ti == 0 ? off : ti == 1 ? off >> 8 : ti < tb - 1 ? 255u : p2 >> 16);
+                    } else {
+                        const uint32_t mcode = (uint32_t)__builtin_amdgcn_readlane((int)vmcode, (int)k);
+                        if (lane == 0) *q = (uint8_t)token;
+                        q += 1;
+                        if (lit >= 15) { emit_len_ext(q, lit - 15); q += len_ext_bytes(lit); }
+                        wave_copy_disjoint(q, ls, lit);
+                        q += lit;
+                        if (lane == 0) { q[0] = (uint8_t)off; q[1] = (uint8_t)(off >> 8); }
+                        q += 2;
+                        if (mcode >= 15) emit_len_ext(q, mcode - 15);
+                    }
+                }
+                o += tot_sz; lp += tot_adv;
+                continue;
+            }
             for (uint32_t k = 0; k < nb; k++) {
                 const uint32_t r = r0 + k;
                 if (ent && (r % IX_STRIDE) == 0 && lane == 0) {
@@ -1239,6 +1284,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_emit_gather(const uint8_t
         uint32_t tot_sz, tot_adv;
         const uint32_t so = scan(act ? 1 + le + lit + 2 + me : 0u, tot_sz);
         const uint32_t sa = scan(act ? lit + mlen : 0u, tot_adv);
+        if (split && (r0 / WAVE) % nsub != sub) { lp_off += tot_adv; o_off += tot_sz; continue; }      // (another wave's batch - only its sizes are mine to know)
         uint8_t* ob = dst + o_off;
         const uint8_t* sb = src + lp_off;
         // ---- control bytes: every lane its own record (long length runs are rare: a lane loops over them) ----
@@ -1326,7 +1372,7 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_emit_gather(const uint8_t
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();     // tables are rewritten by the next batch
         lp_off += tot_adv; o_off += tot_sz;
     }
-    if (ci.flags & 2u) {                                   // last chunk: final literal-only sequence
+    if ((ci.flags & 2u) && sub == 0) {                     // last chunk: final literal-only sequence
         uint8_t* o = dst + o_off;
         const uint32_t lit = ci.nrec ? ci.tail_lit : ci.tail_lit + ci.carry_in;
         if (lane == 0) *o = (uint8_t)((lit < 15 ? lit : 15) << 4);

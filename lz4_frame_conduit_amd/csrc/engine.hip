@@ -322,7 +322,13 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     tick(1, true);
     if (g.n_chunks) {
         tick(2, false);
-        hipLaunchKernelGGL((k_emit_gather<W>), dim3((g.n_chunks + W - 1) / W), dim3(64 * W), 0, st, j.d_src, g, (const ChunkInfo*)info.p,
+        // (few chunks - the streaming API's one block per call: the four waves of a workgroup share a chunk instead of taking one each)
+        const bool e2_split = g.n_chunks <= 512;
+        if (e2_split)
+            hipLaunchKernelGGL((k_emit_gather<W, true>), dim3(g.n_chunks), dim3(64 * W), 0, st, j.d_src, g, (const ChunkInfo*)info.p,
+                               (const uint64_t*)recs.p, d_dst, (const BlockOut*)d_table, d_index);
+        else
+        hipLaunchKernelGGL((k_emit_gather<W, false>), dim3((g.n_chunks + W - 1) / W), dim3(64 * W), 0, st, j.d_src, g, (const ChunkInfo*)info.p,
                            (const uint64_t*)recs.p, d_dst, (const BlockOut*)d_table, d_index);
         tick(2, true);
         if (j.block_checksum) {
