@@ -394,7 +394,7 @@ def main():
             t6_ = time.perf_counter(); rb, _ = oracle.decompress_frame(ref, cap=m + 64); t7_ = time.perf_counter()
             g = m / GIB
             return {"what": "Baseline B: the reference's call pattern (Conduit.hsc:457-533, :598-701; 16 KiB slices, default preferences = 64 KiB linked blocks) on 32 MiB: "
-                            "this library's twelve LZ4F_* functions (every completed block: one DMA up out of page-locked staging, five launches, one DMA back, one synchronisation - ~100 us of kernels for 64 KiB that one CPU core encodes in 60: a synchronous block-at-a-time API is the one shape a GPU cannot win, see DESIGN.md section 7) vs the CPU codec (oracle port, 1 thread) driven the same way",
+                            "this library's twelve LZ4F_* functions (every completed block: one DMA up out of page-locked staging, three launches, one DMA back, one synchronisation - ~46 us of kernels for 64 KiB that one CPU core encodes in 60: a synchronous block-at-a-time API is the one shape a GPU cannot win, see DESIGN.md section 7) vs the CPU codec (oracle port, 1 thread) driven the same way",
                     "gpu_library": {"compress_GiBs": round(g / (t1_ - t0_), 3), "decompress_GiBs": round(g / (t3_ - t2_), 3), "roundtrip_verified": good},
                     "cpu_1_thread": {"compress_GiBs": round(g / (t5_ - t4_), 3), "decompress_GiBs": round(g / (t7_ - t6_), 3), "kind": "port", "roundtrip_verified": rb == data}}
         if want("replay"): side["conduit_replay"] = leg(conduit_replay)
