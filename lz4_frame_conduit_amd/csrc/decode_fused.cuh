@@ -55,6 +55,7 @@ struct alignas(16) FzShared {
     uint32_t produced;                          // slots the parser has published
     uint32_t total_slots;                       // valid once `finished` is set
     uint32_t last_count;                        // descriptors in the last slot
+    uint32_t per_slot;                          // parser: descriptors in every other slot (64, or 8 for a small block)
     uint32_t finished;                          // parser is done (ok or not)
     uint32_t match_done;                        // slots that are complete, in slot order (advanced over slot_done by whoever finishes)
     uint32_t slot_done[C::RING];                // [slot % RING] == slot + 1: that slot's copies are all in memory
@@ -157,6 +158,10 @@ __device__ __forceinline__ void fz_parser(FzShared<C>& sh, const uint8_t* __rest
     // it for 64 sequences at once: fetch the offset (2 bytes behind the literals, straight from the payload in L2), apply the
     // output-side rules, pack the descriptor.  Input-side rules stay on the chain: they are what keeps it inside the payload.
     uint32_t v_src = 0, v_lit = 0, v_op = 0, v_ml = 0;
+    // descriptors per ring slot: 64 - or 8 for a small block (under 96 KiB of payload: the streaming API's 64 KiB block is 64 sequences of the
+    // bench input), whose one slot of 64 would reach ONE copier wave, and only when the whole block is parsed: parse 40 us, then copy 25
+    const uint32_t plog = csize < (96u << 10) ? 3u : 6u, pmask = (1u << plog) - 1u;
+    if (lane == 0) sh.per_slot = pmask + 1;                                   // (read by the copiers with the first slot: a wave's LDS operations are performed in order)
     const uint32_t hist_reach = hist > 65536 ? 65536u : (uint32_t)hist;     // offsets are <= 65535: more history is not distinguishable
     // rules that need the offset / the output position; returns false if a sequence of the slot breaks one
     auto finish_slot = [&](uint32_t count) -> bool {
@@ -240,33 +245,33 @@ __device__ __forceinline__ void fz_parser(FzShared<C>& sh, const uint8_t* __rest
         }
         fin |= bad;
         if (fin == 0) {                                                      // record it
-            const uint32_t slot = nseq & 63;
+            const uint32_t slot = nseq & pmask;
             // (gfx9: one scalar operand per VALU instruction, so the lane number travels in M0 - which is the compiler's, hence kept)
             uint32_t keep;
             asm("s_mov_b32 %4, m0\n\ts_mov_b32 m0, %5\n\tv_writelane_b32 %0, %6, m0\n\tv_writelane_b32 %1, %7, m0\n\tv_writelane_b32 %2, %8, m0\n\tv_writelane_b32 %3, %9, m0\n\ts_mov_b32 m0, %4"
                 : "+v"(v_src), "+v"(v_lit), "+v"(v_op), "+v"(v_ml), "=&s"(keep) : "s"(slot), "s"(p), "s"(lit), "s"(op), "s"(mlen));
             nseq++;
             op += lit + mlen;
-            if (slot == 63) {
-                if (finish_slot(64)) publish((nseq >> 6) - 1);
-                else { fin |= 1u; nseq -= 64; }                               // (nothing of a slot with a bad sequence is published)
+            if (slot == pmask) {
+                if (finish_slot(pmask + 1)) publish((nseq >> plog) - 1);
+                else { fin |= 1u; nseq -= pmask + 1; }                        // (nothing of a slot with a bad sequence is published)
             }
             pos = npos;
             fin |= is_last ? 2u : (pos >= csize ? 1u : 0u);
         }
     }
-    if ((fin & 1u) == 0 && (nseq & 63) && !finish_slot(nseq & 63)) fin |= 1u;    // the partial last slot
+    if ((fin & 1u) == 0 && (nseq & pmask) && !finish_slot(nseq & pmask)) fin |= 1u;    // the partial last slot
     if (fin & 1u) status = 1;
     // final bookkeeping.  Order matters for the partial last slot: its size must be readable by whoever sees it
     // published, so totals and `finished` are written BEFORE `produced` is bumped for it (LDS ops of one wave are
     // performed in order; a copier reads `produced` first, then `finished`).
-    const uint32_t full = nseq >> 6, part = (status == 0) ? (nseq & 63) : 0;
+    const uint32_t full = nseq >> plog, part = (status == 0) ? (nseq & pmask) : 0;
     if (part) {
         while (full >= lds_peek(&sh.match_done) + C::RING) __builtin_amdgcn_s_sleep(8);
         sh.ring[full % C::RING][lane] = uint4{d0, d1, d2, d3};
     }
     sh.total_slots = status ? lds_peek(&sh.produced) : full + (part ? 1u : 0u);       // (all lanes store the same values)
-    sh.last_count = part ? part : 64;
+    sh.last_count = part ? part : pmask + 1;
     sh.out_size = op;
     sh.status = status ? -1 : 0;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -362,7 +367,7 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
         __builtin_amdgcn_s_setprio(1);                                       // copying beats polling
         const uint4 d = sh.ring[slot % C::RING][lane];
         // descriptors in this slot: 64, except a partial last slot -- which is published only after `finished`
-        uint32_t count = 64;
+        uint32_t count = FED ? 64u : lds_peek(&sh.per_slot);                // (parser: 64 per slot, 8 for a small block)
         if (FED) count = lds_peek(&sh.slot_cnt[slot % C::RING]);
         else if (lds_peek(&sh.finished) && slot + 1 == lds_peek(&sh.total_slots)) count = lds_peek(&sh.last_count);
         count = uni(count);
