@@ -199,10 +199,22 @@ __global__ __launch_bounds__(128) void k_spx_index(const uint8_t* __restrict__ f
             // (a lane that started without a pair to go by - none in SPX_SCAN bytes - may stand in a literal run longer than that, where its
             // chain crawls ~20 bytes per hop: if it makes less than an eighth of the way per hop that the probe saw sequences make in this
             // frame, it gives up after 64 hops and the stitching thread walks the stretch)
+            // A lane that started at a pair may crawl as well: a wrong guess that looked like a token - a handful per 4 GiB - makes 900 hops
+            // through its 32 KiB before it falls into step, and in most frames the whole kernel waited 0.6 ms for that one lane.  (The probe
+            // cannot say what a hop should make where every block begins with a long literal run: it then has nothing to count.)  Such a
+            // lane's premise was a token that announces a long literal run, in a stretch made of them; a chain through random bytes finds
+            // one token in sixteen like that.  After 64 hops with fewer than half of them: it gives up, and the stitching thread walks
+            // the stretch.
             const uint32_t slow = (u && s_g[u] == u * SPX_SEG && only_if) ? only_if[1] / 8u : 0u;
+            const bool by_pair = u && s_g[u] != u * SPX_SEG;
+            uint32_t longs = 0;
             for (uint32_t hops = 0;; hops++) {
                 if (c.pos >= stop) { pb = SpxPoint{c.pos, c.seq, c.out}; break; }
-                if (slow && (hops & 63u) == 63u && c.pos - s_g[u] < hops * slow) break;
+                if ((hops & 63u) == 63u) {
+                    if (slow && c.pos - s_g[u] < hops * slow) break;
+                    if (by_pair && longs * 2u < hops) break;
+                }
+                longs += ((uint32_t)c.w & 0xF0u) == 0xF0u ? 1u : 0u;
 #ifdef SPX_PROF
                 if (hops > SPX_LANE_HOPS) atomicAdd(&flags[48], 1u);
 #endif
