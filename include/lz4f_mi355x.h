@@ -226,10 +226,15 @@ LZ4F_MI355X_API size_t lz4f_mi355x_engine_set_deterministic(lz4f_mi355x_engine* 
  *   [7] finish  [8] decode: parse kernel  [9] decode: copy kernel
  *   [10] the whole compress call  [11] the whole decompress call (first kernel's start to last kernel's end on the engine's stream:
  *        the block-checksum verification runs beside the decode kernels on a stream of the engine's own, so [5] + [6] > [11])
- * entries of kernels that did not run are 0. */
+ * entries of kernels that did not run are 0.
+ * get_timing_n fills the first min(n, LZ4F_MI355X_TIMING_SLOTS) slots of a float[n] - the call to use: the slot count has grown
+ * (10 in rounds 1-2, 12 since round 3) and may grow again.  get_timing (no capacity argument) keeps its ORIGINAL contract and
+ * writes exactly LZ4F_MI355X_TIMING_SLOTS_V1 = 10 floats, so a caller built against an older header is never overrun. */
 #define LZ4F_MI355X_TIMING_SLOTS 12
+#define LZ4F_MI355X_TIMING_SLOTS_V1 10
 LZ4F_MI355X_API size_t lz4f_mi355x_engine_set_timing(lz4f_mi355x_engine* e, int enable);
 LZ4F_MI355X_API size_t lz4f_mi355x_engine_get_timing(lz4f_mi355x_engine* e, float* ms);
+LZ4F_MI355X_API size_t lz4f_mi355x_engine_get_timing_n(lz4f_mi355x_engine* e, float* ms, size_t n);
 
 /* result record the device writes; read it back after synchronising the stream */
 typedef struct {

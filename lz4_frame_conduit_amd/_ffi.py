@@ -73,7 +73,8 @@ _SIGS = {
     "lz4f_mi355x_engine_create": (c_size_t, [ctypes.POINTER(c_void_p), ctypes.c_int, c_void_p, ctypes.c_int]), "lz4f_mi355x_engine_free": (c_size_t, [c_void_p]),
     "lz4f_mi355x_engine_stream": (c_void_p, [c_void_p]),
     "lz4f_mi355x_engine_set_deterministic": (c_size_t, [c_void_p, ctypes.c_int]),
-    "lz4f_mi355x_engine_set_timing": (c_size_t, [c_void_p, ctypes.c_int]), "lz4f_mi355x_engine_get_timing": (c_size_t, [c_void_p, ctypes.POINTER(ctypes.c_float)]), "lz4f_mi355x_dev_workspace_size": (c_size_t, [c_size_t, PP]),
+    "lz4f_mi355x_engine_set_timing": (c_size_t, [c_void_p, ctypes.c_int]), "lz4f_mi355x_engine_get_timing": (c_size_t, [c_void_p, ctypes.POINTER(ctypes.c_float)]),
+    "lz4f_mi355x_engine_get_timing_n": (c_size_t, [c_void_p, ctypes.POINTER(ctypes.c_float), c_size_t]), "lz4f_mi355x_dev_workspace_size": (c_size_t, [c_size_t, PP]),
     "lz4f_mi355x_dev_compressFrame": (c_size_t, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, PP, c_void_p, c_void_p]),
     "lz4f_mi355x_dev_decompressFrame": (c_size_t, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]),
     "lz4f_mi355x_dev_index_size": (c_size_t, [c_size_t, PP]),

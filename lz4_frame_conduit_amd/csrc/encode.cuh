@@ -153,6 +153,20 @@ static_assert(64 * E1_WAVES >= E1_NSLICE, "a thread per slice when the lists are
 #ifndef E1_V4
 #define E1_V4 1
 #endif
+// Round 4.  Sparse data (long sequences: the mode word says so) is searched from stride 4 on instead of 1: a grab of the bench input is
+// 512 random bytes and a 512-byte copy, and strides 1, 2 / 3, 4 / 5, 6 took 2.8 probe iterations to get across the random half where
+// 4, 5 / 6, 7 take 1.2 - the match is found a few bytes late and the backward extension recovers its start, as it does for liblz4's
+// own skipping.  Measured on the bench input (tools/ab_run.py): stride 1: 3.66-3.69 ms, ratio 1.9613; 2: 3.57; 3: 3.22; 4: 3.14, 1.9507;
+// 5: 3.16; 6: 3.06 (with E1_IP2 = 0); 8: 2.90 but ratio 1.878, below liblz4's 1.944.  Dense data (text) never gets here.  What it costs
+// elsewhere (tools/ratio_sparse.py, size against liblz4's): rows of 128..2048 bytes +1.0..1.5 %, random-length copies +1 %, structured +1.5..3 %.
+#ifndef E1_STEP0
+#define E1_STEP0 4
+#endif
+// liblz4 also indexes ip - 2 behind a match; here that is one more LDS round trip per match for nothing measurable (bench input: ratio
+// 1.9615 without against 1.9613 with, text 1.8584 both; 3.56 against 3.66 ms)
+#ifndef E1_IP2
+#define E1_IP2 0
+#endif
 constexpr uint32_t E1_GRAB_SPARSE = E1_GRAB, E1_GRAB_DENSE = E1_GRAB_D, E1_PROBE_SLICES = 16, E1_DENSE_HITS = 24;
 
 // 4 / 8 bytes at any byte position of the ring.  (A byte-unaligned ds_read_b32 / _b64 is legal on gfx950 but keeps the LDS busy
@@ -527,7 +541,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                 if (te - MINMATCH < last_start) last_start = te - MINMATCH;
                 if (bend - MFLIMIT < last_start) last_start = bend - MFLIMIT;
                 const uint32_t floor_b = ip;                               // backward extension stops here
-                uint32_t step = 1, two = opener ? 0u : 1u;
+                uint32_t step = (E1_STEP0 > 1 && mode == 1 && !opener) ? (uint32_t)E1_STEP0 : 1u, two = opener ? 0u : 1u;
                 E1DBG(uint32_t it = 0;)
                 while (ip <= last_start) {
                     E1DBG(if (++it > 100000) { if (lane == 0) { atomicAdd((unsigned long long*)&scratch[E1_DBG_AT + 1], 1ull); scratch[E1_DBG_AT + 8] = ((uint64_t)ip << 32) | last_start; scratch[E1_DBG_AT + 9] = ((uint64_t)step << 32) | si; } break; })
@@ -762,7 +776,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                     atomicMax(lane == 0 ? &sh.cov : &sh.idle[lane], ip);
                     // like the CPU encoder, also index ip - 2
                     E1DBG(a_hit += clock64() - z2;)
-                    if (ip >= low + 2 && ip + 2 <= te) { const uint32_t q2 = ip - 2, hv2 = e1_mix(e1_ld32(sh.ring, q2)); *(lane == 0 ? &sh.table[e1_slot(hv2)] : (uint16_t*)&sh.idle[lane]) = (uint16_t)q2; *(lane == 0 ? &sh.tags[e1_slot(hv2)] : (uint8_t*)&sh.idle[lane]) = (uint8_t)e1_tag(hv2); }
+                    if (E1_IP2 && ip >= low + 2 && ip + 2 <= te) { const uint32_t q2 = ip - 2, hv2 = e1_mix(e1_ld32(sh.ring, q2)); *(lane == 0 ? &sh.table[e1_slot(hv2)] : (uint16_t*)&sh.idle[lane]) = (uint16_t)q2; *(lane == 0 ? &sh.tags[e1_slot(hv2)] : (uint8_t*)&sh.idle[lane]) = (uint8_t)e1_tag(hv2); }
                 }
             }
             // (lane k for slice si + k; the other lanes store to words of their own: no branch, no 64 stores to one address)

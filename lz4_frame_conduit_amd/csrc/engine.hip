@@ -199,6 +199,9 @@ size_t lz4f_mi355x_engine::sync()
 {
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    // (work forked onto the second stream that the main stream never joined - a call that returned an error behind the fork: a caller that
+    // frees its buffers after sync() must not race it)
+    if (aux_pending && aux_stream) { HIP_TRY(hipStreamSynchronize((hipStream_t)aux_stream)); aux_pending = false; }
     return 0;
 }
 
@@ -367,6 +370,12 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
     for (int i = 4; i < 10; i++) ev_used[i] = false;
     ev_used[11] = false;
     if (aux_pending) { HIP_TRY(hipStreamWaitEvent(st, (hipEvent_t)ev_join, 0)); aux_pending = false; }      // (a call that left early: its forked work first)
+    // every exit behind the fork joins: an error return (allocation, a HIP call) leaves the main stream waiting for the forked verification, so
+    // that whatever the caller enqueues or frees behind a synchronisation of its stream comes after the kernel that still reads the frame
+    struct AuxJoin {
+        lz4f_mi355x_engine* e; hipStream_t st;
+        ~AuxJoin() { if (e->aux_pending && hipStreamWaitEvent(st, (hipEvent_t)e->ev_join, 0) == hipSuccess) e->aux_pending = false; }
+    } aux_join{this, st};
     tick(11, false);
     if (j.d_table || j.table_in_place || j.table_direct) {
         // caller-supplied table: work on a copy (decode overwrites dst_size); table_direct: the engine's own staging copy, used where it lies
@@ -751,7 +760,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
     const bool check_here = n_max <= 64;                              // (the finishing wave looks at a few blocks itself: a launch less)
     if (n_max && !check_here) hipLaunchKernelGGL(k_finish_check, dim3((n_max + 255) / 256), dim3(256), 0, st, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size, (uint32_t*)bad.p);
     hipLaunchKernelGGL(k_finish_decode, dim3(1), dim3(64), 0, st, j.d_dst, tbl, (ResultRec*)d_res, n_max, j.linked ? 1u : 0u, j.block_size,
-                       (const uint32_t*)bad.p, j.block_checksum ? 1u : 0u, plan, ix_flags, check_here ? 1u : 0u);
+                       (const uint32_t*)bad.p, j.block_checksum ? 1u : 0u, plan, ix_flags, check_here ? 1u : 0u, (uint64_t)j.dst_cap);
     if (j.content_checksum && !j.d_table && !j.table_in_place && !j.table_direct && !sw.no_content_check)      // (a whole frame was walked: res->consumed is behind its checksum word)
         hipLaunchKernelGGL(k_xxh32_content, dim3(1), dim3(64), 0, st, (const uint8_t*)j.d_dst, 0ull, (uint8_t*)j.d_frame, (ResultRec*)d_res, 1u);
     tick(7, true);
@@ -1172,12 +1181,13 @@ size_t lz4f_mi355x_engine_set_timing(lz4f_mi355x_engine* e, int enable)
     e->timing = enable != 0;
     return 0;
 }
-size_t lz4f_mi355x_engine_get_timing(lz4f_mi355x_engine* e, float* ms)
+size_t lz4f_mi355x_engine_get_timing(lz4f_mi355x_engine* e, float* ms) { return lz4f_mi355x_engine_get_timing_n(e, ms, LZ4F_MI355X_TIMING_SLOTS_V1); }
+size_t lz4f_mi355x_engine_get_timing_n(lz4f_mi355x_engine* e, float* ms, size_t n)
 {
     if (!e || !ms) return make_err(LZ4F_ERROR_GENERIC);
     size_t r = e->sync();
     if (is_err(r)) return r;
-    for (int s = 0; s < LZ4F_MI355X_TIMING_SLOTS; s++) {
+    for (int s = 0; s < LZ4F_MI355X_TIMING_SLOTS && (size_t)s < n; s++) {
         ms[s] = 0.f;
         if (e->ev_used[s] && e->ev[2 * s] && e->ev[2 * s + 1]) {
             float t = 0.f;

@@ -225,9 +225,6 @@ __global__ __launch_bounds__(64) void k_xxh32_content(const uint8_t* __restrict_
 }
 
 // ------------------------------- frame walk -----------------------------------------------------
-#ifndef WK_AHEAD          // lines per lane the serial walk touches around where the size word after the next one should be (1: 8 KiB, 2: 16 KiB, 4: 32 KiB)
-#define WK_AHEAD 1
-#endif
 __device__ __forceinline__ uint32_t rd32_any(const uint8_t* p)
 {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
@@ -252,7 +249,11 @@ __global__ __launch_bounds__(64) void k_walk_frame(const uint8_t* __restrict__ f
     if (walked && *walked) return;                                      // the parallel walk (below) has written table and result
     const uint32_t lane = lane_id();
     ResultRec r; r.size = 0; r.consumed = 0; r.status = ST_OK; r.n_blocks = 0; r.first_bad_block = 0xFFFFFFFFu; r.flags = 0;
-    auto fail = [&](uint32_t st) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory", "v250", "v251", "v252", "v253"); r.status = st; *res = r; };      // (a read-ahead may be in flight)
+    // (the read-ahead's landing place: LDS, by LDS-DMA - a load without a destination register, so nothing the compiler allocates can be hit by
+    // one that is still in flight; round 3 named v250..v253 in a clobber list, which reserves nothing between statements)
+    __shared__ uint32_t ra_sink[WAVE];
+    const uint32_t sink0 = uni((uint32_t)(uintptr_t)(lptr_t)ra_sink);
+    auto fail = [&](uint32_t st) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); r.status = st; *res = r; };      // (a read-ahead may be in flight)
     if (frame_cap < 7) return fail(12);                              // frameHeader_incomplete
     const uint32_t magic = rd32_any(frame);
     if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {                      // skippable frame: no output
@@ -286,9 +287,9 @@ __global__ __launch_bounds__(64) void k_walk_frame(const uint8_t* __restrict__ f
     // caught about half of the hops of the bench's frame).  A right guess makes that hop an L2 hit, a wrong one costs nothing: the
     // words read ahead are only looked at to keep the loads alive.
     // (The read-ahead must not be waited for: memory operations return in order, so the next size word is asked for FIRST and the
-    // read-ahead behind it, and the wait is for all but the four youngest - which the compiler cannot be told, hence the asm.  The
-    // read-ahead lands in v250..v253, named in the asm and in its clobber list: registers the compiler keeps out of for the whole
-    // kernel, so a load that is still in flight when the next statement runs cannot land in a register that has got another job.)
+    // read-ahead behind it, and the wait is for all but the youngest - which the compiler cannot be told, hence the asm.  The
+    // read-ahead is a global_load_lds_dword: it lands in 256 bytes of LDS nobody reads, no register is written.  Two or four lines
+    // per lane measured slower than one - 0.478 / 0.600 against 0.451 ms for the bench frame - and are gone.)
     if (frame_cap - pos < 4) return fail(12);
     uint32_t w = *(const u32_ua*)(frame + pos);
     for (;;) {
@@ -305,34 +306,15 @@ __global__ __launch_bounds__(64) void k_walk_frame(const uint8_t* __restrict__ f
         pos += (uint64_t)csz + 4 * bck;
         n++;
         if (frame_cap - pos < 4) return fail(12);
-#if WK_AHEAD == 4
-        const uint64_t guess = pos + 4 + csz + 4 * bck + (uint64_t)lane * 128u;          // (lane 0 of the third group = the guess itself)
-        const bool inside = guess >= 16384u + 4u && guess + 16384u + 4u <= frame_cap;
-        const uint8_t* pw = frame + pos;
-        const uint8_t* pa = inside ? frame + ((guess - 16384u) & ~(uint64_t)3) : pw;
-        const uint64_t st8 = inside ? 8192u : 0u;
-        const uint8_t* pb = pa + st8; const uint8_t* pc = pb + st8; const uint8_t* pd = pc + st8;
-        asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword v250, %2, off\n\tglobal_load_dword v251, %3, off\n\tglobal_load_dword v252, %4, off\n\t"
-                     "global_load_dword v253, %5, off\n\ts_waitcnt vmcnt(4)"
-                     : "=&v"(w) : "v"(pw), "v"(pa), "v"(pb), "v"(pc), "v"(pd) : "memory", "v250", "v251", "v252", "v253");
-#elif WK_AHEAD == 2
-        const uint64_t guess = pos + 4 + csz + 4 * bck + (uint64_t)lane * 128u;          // (lane 0 of the second group = the guess itself)
-        const bool inside = guess >= 8192u + 4u && guess + 8192u + 4u <= frame_cap;
-        const uint8_t* pw = frame + pos;
-        const uint8_t* pa = inside ? frame + ((guess - 8192u) & ~(uint64_t)3) : pw;
-        const uint8_t* pb = pa + (inside ? 8192u : 0u);
-        asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword v250, %2, off\n\tglobal_load_dword v251, %3, off\n\ts_waitcnt vmcnt(2)"
-                     : "=&v"(w) : "v"(pw), "v"(pa), "v"(pb) : "memory", "v250", "v251", "v252", "v253");
-#else
         const uint64_t guess = pos + 4 + csz + 4 * bck + (uint64_t)lane * 128u;          // lane 32 = the guess itself
         const bool inside = guess >= 4096u + 4u && guess - 4096u + 4u <= frame_cap;
         const uint8_t* pw = frame + pos;
         const uint8_t* pa = inside ? frame + ((guess - 4096u) & ~(uint64_t)3) : pw;
-        asm volatile("global_load_dword %0, %1, off\n\tglobal_load_dword v250, %2, off\n\ts_waitcnt vmcnt(1)"
-                     : "=&v"(w) : "v"(pw), "v"(pa) : "memory", "v250", "v251", "v252", "v253");
-#endif
+        uint32_t keep;
+        asm volatile("global_load_dword %0, %2, off\n\ts_mov_b32 %1, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dword %3, off\n\ts_mov_b32 m0, %1\n\ts_waitcnt vmcnt(1)"
+                     : "=&v"(w), "=&s"(keep) : "v"(pw), "v"(pa), "s"(sink0) : "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory", "v250", "v251", "v252", "v253");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if ((flg >> 2) & 1) { if (frame_cap - pos < 4) return fail(12); pos += 4; }   // content checksum: verified behind the decode (k_xxh32_content)
     r.n_blocks = n; r.consumed = pos; r.size = content;             // size = declared content size until decode fills it
     *res = r;
@@ -937,7 +919,8 @@ __global__ __launch_bounds__(256) void k_finish_check(const BlockOut* __restrict
 
 __global__ __launch_bounds__(64) void k_finish_decode(uint8_t* dst, BlockOut* __restrict__ table, ResultRec* res, uint32_t n_max,
                                                       uint32_t linked, uint32_t block_size, const uint32_t* __restrict__ bad_ck, uint32_t with_ck,
-                                                      uint32_t plan = 0, const uint32_t* __restrict__ ix_flags = nullptr, uint32_t check_here = 0)
+                                                      uint32_t plan = 0, const uint32_t* __restrict__ ix_flags = nullptr, uint32_t check_here = 0,
+                                                      uint64_t dst_cap = ~0ull)
 {   // check_here (n_max <= 64): what k_finish_check leaves in bad_ck[1], [2], [4..5] is worked out by this wave itself - a launch less for calls of a few blocks
     // which way the call went (lz4f_mi355x.h: LZ4F_MI355X_PATH_*): what the host launched, and whether the indexed kernels gave up
     if (lane_id() == 0) res->flags = (res->flags & 0xFFFu) | (plan << 12) | ((ix_flags && *ix_flags) ? (LZ4F_MI355X_PATH_INDEX_DROPPED << 12) : 0u);
@@ -968,7 +951,11 @@ __global__ __launch_bounds__(64) void k_finish_decode(uint8_t* dst, BlockOut* __
         return;
     }
     if (first_bad != 0xFFFFFFFFu) {
-        if (lane == 0) { res->status = (bad_kind == (uint32_t)-2) ? ST_DSTSMALL : ST_GENERIC; res->first_bad_block = first_bad; }
+        // (a block that did not decode into LESS room than a whole block is "the output does not fit", as the oracle's frame decoder and
+        // the host paths call it: oracle/orc_lz4frame.c "room < bs ? dstMaxSize_tooSmall : GENERIC")
+        const uint64_t at_bad = table[first_bad].dst_off;
+        const bool short_room = at_bad <= dst_cap && dst_cap - at_bad < block_size;
+        if (lane == 0) { res->status = (bad_kind == (uint32_t)-2 || short_room) ? ST_DSTSMALL : ST_GENERIC; res->first_bad_block = first_bad; }
         return;
     }
     // usual case, checked 64 blocks per step: every block already sits where its predecessors end (all blocks but

@@ -57,8 +57,8 @@ class Engine:
         _chk(self.L, self.L.lz4f_mi355x_engine_set_timing(self.h, 1 if on else 0))
 
     def get_timing(self) -> dict:
-        ms = (ctypes.c_float * 12)()
-        _chk(self.L, self.L.lz4f_mi355x_engine_get_timing(self.h, ms))
+        ms = (ctypes.c_float * len(self.TIMING_SLOTS))()
+        _chk(self.L, self.L.lz4f_mi355x_engine_get_timing_n(self.h, ms, len(self.TIMING_SLOTS)))
         return dict(zip(self.TIMING_SLOTS, [float(x) for x in ms]))
 
     # -- helpers

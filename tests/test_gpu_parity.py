@@ -1139,6 +1139,134 @@ def test_foreign_big_independent_blocks_stretch_parallel(L):
     assert not diff, diff[:5]
 
 
+def _lz4_seq(lit: bytes, mlen: int, off: int) -> bytes:
+    """One LZ4 sequence (token, literal length bytes, literals, offset, match length bytes); mlen == 0: the block's last, literals only."""
+    def ext(v):
+        out = bytearray()
+        while v >= 255: out.append(255); v -= 255
+        out.append(v); return bytes(out)
+    ll, ml = len(lit), (mlen - 4 if mlen else 0)
+    b = bytearray([(min(ll, 15) << 4) | min(ml, 15)])
+    if ll >= 15: b += ext(ll - 15)
+    b += lit
+    if mlen:
+        b += bytes([off & 255, off >> 8])
+        if ml >= 15: b += ext(ml - 15)
+    return bytes(b)
+
+
+@pytest.mark.gpu
+def test_foreign_frames_never_write_past_capacity(L):
+    """Foreign frames of big independent blocks go through the stretch-parallel self-index (decode_spx.cuh), whose scan learns what the
+    PAYLOADS claim to decode to.  Those claims must never size a write: an output buffer one byte short, and a block whose last match
+    makes it decode to block_size + k, are errors (liblz4: dstMaxSize_tooSmall / decompressionFailed) and the bytes behind the
+    caller's capacity stay untouched - through the device-resident call and the host-pointer call."""
+    import torch
+    from lz4_frame_conduit_amd.device import Engine, DeviceCodecError
+    rng = np.random.default_rng(5)
+    GUARD = 1 << 20
+    eng = Engine(0)
+
+    def device_decode(frame: bytes, cap: int):
+        dev = torch.from_numpy(np.frombuffer(frame + bytes(32), dtype=np.uint8).copy()).cuda()
+        back = torch.full((cap + GUARD,), 0xA5, dtype=torch.uint8, device="cuda")
+        try:
+            eng.decompress_frame_async(dev, len(frame), back[:cap]); r = eng.result(); verdict = "ok"
+        except DeviceCodecError as e:
+            r, verdict = None, str(e)
+        torch.cuda.synchronize()
+        assert bool((back[cap:] == 0xA5).all()), "bytes behind the caller's capacity were written"
+        return r, verdict, back
+
+    # (1) liblz4's framing (-B7, -B6, -B5 independent) of long sequences, capacity one byte (and one block) short
+    data = np.concatenate([datagen.synth50(9 << 20, 3), rng.integers(0, 256, 123457, dtype=np.uint8)])
+    for kw in (dict(bsid=7, indep=1), dict(bsid=6, indep=1, bck=1), dict(bsid=5, indep=1)):
+        fr = oracle.conduit_compress(data.tobytes(), oracle.mkprefs(**kw))
+        r, verdict, back = device_decode(fr, len(data))
+        assert verdict == "ok" and r.size == len(data) and back[:len(data)].cpu().numpy().tobytes() == data.tobytes(), (kw, verdict)
+        for short in (1, 70000, (4 << 20) + 5):
+            r, verdict, _ = device_decode(fr, len(data) - short)
+            assert verdict != "ok" and "dstMaxSize_tooSmall" in verdict, (kw, short, verdict)
+            with pytest.raises(RuntimeError, match="dstMaxSize_tooSmall"):
+                gpu_decompress_frame(L, fr, len(data) - short)
+
+    # (2) a hand-made frame: four 256 KiB blocks of 1 KiB sequences (600 literals + a 424-byte copy of them), block `odd` has one match
+    # that is k bytes too long - it decodes to 256 KiB + k
+    bs = 256 << 10
+    def block(extra: int) -> bytes:
+        out = bytearray()
+        nseq = bs // 1024
+        for q in range(nseq - 1):
+            out += _lz4_seq(rng.integers(0, 256, 600, dtype=np.uint8).tobytes(), 424 + (extra if q == nseq // 2 else 0), 600)
+        out += _lz4_seq(rng.integers(0, 256, 600, dtype=np.uint8).tobytes(), 412, 600)
+        out += _lz4_seq(rng.integers(0, 256, 12, dtype=np.uint8).tobytes(), 0, 0)
+        return bytes(out)
+    header = oracle.conduit_compress(b"", oracle.mkprefs(bsid=5, indep=1))[:7]
+    def frame_of(blocks):
+        f = bytearray(header)
+        for b in blocks: f += len(b).to_bytes(4, "little") + b
+        return bytes(f) + bytes(4)
+    good = frame_of([block(0) for _ in range(4)])
+    want, _ = oracle.decompress_frame(good, 4 * bs + 8)
+    assert len(want) == 4 * bs
+    r, verdict, back = device_decode(good, 4 * bs)
+    assert verdict == "ok" and r.size == 4 * bs and back[:4 * bs].cpu().numpy().tobytes() == want
+    for odd, k in ((1, 1), (1, 300), (3, 70000), (0, 5), (2, (4 << 20))):
+        bad = frame_of([block(k if i == odd else 0) for i in range(4)])
+        with pytest.raises(oracle.OracleError):
+            oracle.decompress_frame(bad, 4 * bs + (8 << 20))
+        for cap in (4 * bs, 4 * bs + k):
+            r, verdict, _ = device_decode(bad, cap)
+            assert verdict != "ok", (odd, k, cap)
+        with pytest.raises(RuntimeError):
+            gpu_decompress_frame(L, bad, 4 * bs + k)
+    eng.close()
+
+
+@pytest.mark.gpu
+def test_streams_beyond_32_bits_device_resident(L):
+    """The reference tests "more than 32-bit many Bytes" (test/Main.hs:80-84, :107-111: 5 GiB of 0x2A through compress and through
+    decompress).  Here: 5 GiB of 0x2A and 5 GiB of synth50, each through ONE device-resident call each way - positions in the input,
+    in the output and (for the stored case) in the frame all cross 2^32 inside a call - in the `lz4` tool's framing (4 MiB independent
+    blocks), with and without the in-band trailer, and in the conduit's default framing (64 KiB linked blocks); the device compares
+    all 5 GiB with the input, and the oracle decodes the frame's first blocks."""
+    import torch
+    from lz4_frame_conduit_amd.device import Engine, synth50_device
+    n = 5 << 30
+    eng = Engine(0)
+    for kind in ("rep42", "synth50", "random"):
+        if kind == "rep42": src = torch.full((n,), 42, dtype=torch.uint8, device="cuda")
+        elif kind == "synth50": src = synth50_device(n, 4321, "cuda")
+        else: src = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda")                  # stored blocks: the FRAME is beyond 2^32 too
+        back = torch.empty(n + 64, dtype=torch.uint8, device="cuda")
+        for kw, inband in ((dict(bsid=7, indep=1), True), (dict(bsid=7, indep=1), False), (dict(), True)):
+            if kind == "random" and not kw: continue
+            p = prefs_of(kw)
+            frame = torch.empty(eng.frame_bound_inband(n, p), dtype=torch.uint8, device="cuda")
+            eng.compress_async(src, frame, p, inband=inband); r = eng.result()
+            assert r.consumed == n and r.size > 0, (kind, kw, inband)
+            back.fill_(0xA5)
+            eng.decompress_frame_async(frame, int(r.size), back[:n]); r2 = eng.result()
+            assert r2.size == n, (kind, kw, inband, r2.size)
+            assert bool(torch.equal(back[:n], src)) and bool((back[n:] == 0xA5).all()), (kind, kw, inband)
+            if kind == "random": assert r.size > (1 << 32) + (1 << 30)
+            # the oracle on the frame's head: the first blocks decode to the input's first bytes
+            head = frame[:min(int(r.size), 9 << 20)].cpu().numpy().tobytes()
+            bs = 4 << 20 if kw else 64 << 10
+            pos, got = 7, b""
+            while len(got) < 2 * bs and pos + 4 <= len(head):
+                w = int.from_bytes(head[pos:pos + 4], "little"); pos += 4
+                if w == 0: break
+                csz = w & 0x7FFFFFFF
+                if pos + csz > len(head): break
+                got += head[pos:pos + csz] if w >> 31 else oracle.decompress_block(head[pos:pos + csz], bs, got[-65536:] if not kw else b"")
+                pos += csz
+            assert len(got) >= bs and got == src[:len(got)].cpu().numpy().tobytes(), (kind, kw, inband)
+            del frame
+        del src, back
+    eng.close()
+
+
 @pytest.mark.gpu
 def test_decode_path_by_input_class(L):
     """Which kernels a decompress call launches is a function of the call alone - the arguments, the frame's header and trailer,
