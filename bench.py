@@ -9,10 +9,14 @@ One "step" = one pass of the hot path over one batch of synthetic input that is 
   decompress  lz4f_mi355x_dev_decompressFrame on those bytes and nothing else: no block table, no side buffer.  It finds the
               trailer, checks it against the frame, parses per index entry, resolves direct matches, copies.
 both through the C ABI on torch's current stream.  The same LZ4 frame WITHOUT its trailer - what a frame from liblz4 or the
-`lz4` tool looks like to this decoder - is timed after the timed region (`foreign_frame`: seeded size-word walk, stretch-parallel self-index, indexed kernels).
-Workload at every N: BASELINE configs[2] per GPU -- 4 GiB of synth50 (~50 % compressible), 4 MiB independent blocks; frame
-blocks are independent, so ranks shard the stream with no data-path collective ("weak" scaling: every rank gets its own 4 GiB
-with seed 1234+rank).  value = bytes of uncompressed input all ranks processed / max-over-ranks wall time of the K steps.
+`lz4` tool looks like to this decoder - is timed after the timed region (`foreign_frame`: the stream framed by liblz4.so.1 itself, and beside it this
+library's own frame minus its trailer; seeded size-word walk, stretch-parallel self-index, indexed kernels).
+Workload: one GPU: BASELINE configs[2] -- 4 GiB of synth50 (~50 % compressible), 4 MiB independent blocks.  N > 1: configs[3]'s shape --
+every rank its own 8 GiB stream (seed 1234+rank; 8 ranks = the 64 GiB the config names, and every call crosses 2^32 bytes); frame
+blocks are independent, so ranks shard with no data-path collective ("weak" scaling: per-GPU work fixed for N >= 2).
+value = bytes of uncompressed input all ranks processed / max-over-ranks wall time of the K steps.
+`multi_device_host` is the other multi-GPU number: ONE frame in page-locked host memory whose slabs lz4f_mi355x_use_devices deals over
+the N GPUs (rank 0 drives them all after the timed region; one GPU: two logical devices, plumbing only).
 
 Extra objects on the JSON line (all outside the timed region):
   roofline       the kernel with the largest share of the step: algorithmic bytes (U + C per direction) /
@@ -22,6 +26,8 @@ Extra objects on the JSON line (all outside the timed region):
   block_checksum_on   the step with XXH32 block checksums written and verified on the GPU
   cfg2           BASELINE configs[1]: decompress-only, 1 GiB of text pre-framed by liblz4 at 64 KiB independent blocks, bare frame, walk included
   host_to_host   lz4f_mi355x_compressFrame / decompressFrame on host buffers (SURVEY 8d variant H), pageable and page-locked
+  content_checksum_cap   what a frame's content checksum (one serial XXH32 chain) caps a stream at: device wave, host thread
+  multi_device_host      one frame's slabs dealt over N devices, host to host
   conduit_replay the reference's conduit call pattern (Conduit.hsc:457-533, :598-701: 16 KiB slices, default preferences)
                  through this library's twelve LZ4F_* functions, next to the CPU codec driven the same way on one thread
   cpu_baseline   the same blocks through liblz4 (dlopen, kind "reference") or the oracle port, on the host cores,
@@ -94,6 +100,54 @@ def cpu_baseline(block_size: int, sample_bytes: int):
             "ratio": round(u / j["compressed"], 4), "roundtrip_ok": j["roundtrip_ok"]}
 
 
+def liblz4_frame(tile, bsid: int, reps: int):
+    """One LZ4 frame of `reps` copies of the numpy byte array `tile`, independent blocks of size id `bsid`, framed by the REFERENCE's codec:
+    LZ4F_compressFrame of the tile through the installed liblz4.so.1 (else the oracle port, bit-exact with it), the tile's blocks `reps` times
+    between one header and one EndMark (the tile is a whole number of blocks).  -> (numpy frame with 64 spare bytes, frame size, who framed it)"""
+    import numpy as np
+    from lz4_frame_conduit_amd import conduit
+    tile_n = int(tile.size)
+    assert tile_n % (1 << (8 + 2 * bsid)) == 0
+    try:
+        lz = ctypes.CDLL("liblz4.so.1")
+        lz.LZ4F_compressFrameBound.restype = ctypes.c_size_t; lz.LZ4F_compressFrameBound.argtypes = [ctypes.c_size_t, ctypes.c_void_p]
+        lz.LZ4F_compressFrame.restype = ctypes.c_size_t; lz.LZ4F_compressFrame.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        lp = conduit.make_preferences(blockSizeID=bsid, blockMode=1)
+        cap = lz.LZ4F_compressFrameBound(tile_n, ctypes.byref(lp))
+        buf = np.empty(cap, dtype=np.uint8)
+        r_ = lz.LZ4F_compressFrame(buf.ctypes.data_as(ctypes.c_void_p), cap, tile.ctypes.data_as(ctypes.c_void_p), tile_n, ctypes.byref(lp))
+        if r_ < 64 or r_ > cap: raise OSError("LZ4F_compressFrame: %d" % r_)
+        one = buf[:r_]; framer = "liblz4.so.1 %d (LZ4F_compressFrame)" % lz.LZ4_versionNumber()
+    except (OSError, AttributeError):
+        import oracle
+        one = np.frombuffer(oracle.conduit_compress(tile.tobytes(), oracle.mkprefs(bsid=bsid, indep=1)), dtype=np.uint8)
+        framer = "oracle port of liblz4 1.9.3 (bit-exact with it: tests/test_oracle_golden.py)"
+    assert bytes(one[:4]) == b"\x04\x22\x4d\x18" and bytes(one[-4:]) == bytes(4) and one.size > 11
+    body = one[7:-4]
+    host = np.empty(7 + body.size * reps + 4 + 64, dtype=np.uint8)
+    host[:7] = one[:7]
+    for r_ in range(reps): host[7 + r_ * body.size: 7 + (r_ + 1) * body.size] = body
+    fsize = 7 + body.size * reps + 4
+    host[fsize - 4:] = 0
+    return host, fsize, framer
+
+
+def where_am_i():
+    """CPU affinity and NUMA node of the calling thread (the host legs' numbers move with them)."""
+    out = {}
+    try:
+        aff = sorted(os.sched_getaffinity(0)); out["affinity"] = "%d cpus: %d-%d" % (len(aff), aff[0], aff[-1])
+        cpu = None
+        with open("/proc/self/stat") as f: cpu = int(f.read().rsplit(")", 1)[1].split()[36])
+        out["running_on_cpu"] = cpu
+        for nd in sorted(os.listdir("/sys/devices/system/node")):
+            if nd.startswith("node") and os.path.exists("/sys/devices/system/node/%s/cpu%d" % (nd, cpu)): out["numa_node"] = int(nd[4:])
+        out["numa_nodes"] = len([d for d in os.listdir("/sys/devices/system/node") if d.startswith("node")])
+    except Exception as e:      # noqa: BLE001
+        out["note"] = repr(e)
+    return out
+
+
 def leg(fn):
     """A side leg must never take the headline down."""
     try:
@@ -107,7 +161,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--bytes", type=int, default=4 << 30, help="uncompressed bytes per GPU per step")
+    ap.add_argument("--bytes", type=int, default=0, help="uncompressed bytes per GPU per step (default: 4 GiB on one GPU = BASELINE configs[2]; 8 GiB per rank on N > 1, "
+                                                        "so that 8 ranks move the 64 GiB of configs[3] - and every call crosses 2^32 bytes)")
     ap.add_argument("--block-size-id", type=int, default=7, help="4=64KiB 5=256KiB 6=1MiB 7=4MiB")
     ap.add_argument("--block-checksum", type=int, default=0)
     ap.add_argument("--linked", type=int, default=0)
@@ -115,7 +170,7 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="skip the side legs: what the rocprofv3 summaries under profiles/ are taken with, so that their per-kernel averages are the headline launches' only")
     ap.add_argument("--foreign", action="store_true", help="the timed decode gets the bare LZ4 frame (no trailer): walk + self-index + indexed kernels")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
-    ap.add_argument("--legs", default="all", help="comma-separated side legs to run (foreign,bck,cfg2,linked,host,replay); what tools/prof_leg.sh profiles one at a time")
+    ap.add_argument("--legs", default="all", help="comma-separated side legs to run (foreign,bck,cfg2,linked,host,cck,replay,multi); what tools/prof_leg.sh profiles one at a time")
     args = ap.parse_args()
 
     # N > 1 and not yet under a launcher: start N ranks (one process per GPU) as a CHILD process and relay its output - nothing in
@@ -166,7 +221,7 @@ def main():
         torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
 
-    n = args.bytes
+    n = args.bytes if args.bytes else ((4 << 30) if world == 1 else (8 << 30))
     bs = 1 << (8 + 2 * args.block_size_id)
     prefs = conduit.make_preferences(blockSizeID=args.block_size_id, blockMode=0 if args.linked else 1, blockChecksum=args.block_checksum)
     nb = (n + bs - 1) // bs
@@ -230,20 +285,32 @@ def main():
         algo = float(n + frame_only)
 
         def foreign():
-            t = []
-            good = True
-            for _ in range(3):
-                spoil(back)
-                eng.decompress_frame_async(frame, frame_only, back)          # the bare frame: nothing but LZ4
-                rf = eng.result(); tt = eng.get_timing()
-                t.append((tt["decompress_total"], tt["walk"], tt["decode"]))
-                good = good and bool(rf.size == n and torch.equal(back, src))
-            best = min(t)
-            return {"what": "the same LZ4 frame without the trailer (as liblz4 / the lz4 tool would have written it), device-resident, no block table: "
-                            "seeded size-word walk, then the decoder cuts the blocks into stretches itself (decode_spx.cuh) and runs the indexed kernels", "ms": round(best[0], 4), "walk_ms": round(best[1], 4), "decode_ms": round(best[2], 4),
-                    "roundtrip_verified": good,
-                    "roofline": {"bound": "hbm", "achieved": round(algo / (best[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                 "frac": round(algo / (best[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+            def timed(fr, size, expect):
+                t = []; good = True
+                for _ in range(3):
+                    spoil(back)
+                    eng.decompress_frame_async(fr, size, back)
+                    rf = eng.result(); tt = eng.get_timing()
+                    t.append((tt["decompress_total"], tt["walk"], tt["decode"]))
+                    good = good and bool(rf.size == n and rf.consumed == size and torch.equal(back, expect))
+                best = min(t)
+                a_ = float(n + size)
+                return {"ms": round(best[0], 4), "walk_ms": round(best[1], 4), "decode_ms": round(best[2], 4), "frame_bytes": int(size), "roundtrip_verified": good,
+                        "roofline": {"bound": "hbm", "achieved": round(a_ / (best[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                     "frac": round(a_ / (best[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+            # (a) bytes the REFERENCE's codec wrote: LZ4F_compressFrame (liblz4.so.1) of the stream's first 512 MiB, its blocks eight times
+            tile_n = min(n, 512 << 20); reps = n // tile_n
+            host, fsize, framer = liblz4_frame(src[:tile_n].cpu().numpy(), args.block_size_id, reps)
+            f_l = torch.from_numpy(host).to(dev)
+            exp = src[:tile_n].repeat(reps) if reps > 1 else src
+            out_ = timed(f_l, fsize, exp)
+            del f_l, exp
+            # (b) this library's own frame without its trailer (what rounds 2-3 reported here)
+            own = timed(frame, frame_only, src)
+            out_.update({"what": "a bare LZ4 frame (no trailer, no block table), device-resident: seeded size-word walk, then the decoder cuts the blocks into stretches itself "
+                                 "(decode_spx.cuh) and runs the indexed kernels", "framer": framer + ", %d MiB tile x %d" % (tile_n >> 20, reps),
+                         "own_frame_minus_trailer": own})
+            return out_
         if want("foreign"): side["foreign_frame"] = leg(foreign)
 
         def bck_on():
@@ -271,28 +338,8 @@ def main():
             # the oracle port, which is bit-exact with it; the tile's blocks, sixteen times, between one header and one EndMark.
             m, tile_n = 1 << 30, 64 << 20
             tile = datagen.synth_text(tile_n, 99)
-            framer = None
-            try:
-                lz = ctypes.CDLL("liblz4.so.1")
-                lz.LZ4F_compressFrameBound.restype = ctypes.c_size_t; lz.LZ4F_compressFrameBound.argtypes = [ctypes.c_size_t, ctypes.c_void_p]
-                lz.LZ4F_compressFrame.restype = ctypes.c_size_t; lz.LZ4F_compressFrame.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
-                lp = conduit.make_preferences(blockSizeID=4, blockMode=1)
-                cap = lz.LZ4F_compressFrameBound(tile_n, ctypes.byref(lp))
-                buf = ctypes.create_string_buffer(cap)
-                r_ = lz.LZ4F_compressFrame(buf, cap, tile.ctypes.data_as(ctypes.c_void_p), tile_n, ctypes.byref(lp))
-                if r_ < 64 or r_ > cap: raise OSError("LZ4F_compressFrame: %d" % r_)
-                one = buf.raw[:r_]; framer = "liblz4.so.1 %d (LZ4F_compressFrame)" % lz.LZ4_versionNumber()
-            except (OSError, AttributeError):
-                import oracle
-                one = oracle.conduit_compress(tile.tobytes(), oracle.mkprefs(bsid=4, indep=1)); framer = "oracle port of liblz4 1.9.3 (bit-exact with it: tests/test_oracle_golden.py)"
-            assert one[:4] == b"\x04\x22\x4d\x18" and one[-4:] == bytes(4) and len(one) > 11
-            body = np.frombuffer(one[7:-4], dtype=np.uint8)
             reps = m // tile_n
-            host = np.empty(7 + len(body) * reps + 4 + 64, dtype=np.uint8)
-            host[:7] = np.frombuffer(one[:7], dtype=np.uint8)
-            for r_ in range(reps): host[7 + r_ * len(body): 7 + (r_ + 1) * len(body)] = body
-            fsize = 7 + len(body) * reps + 4
-            host[fsize - 4:] = 0
+            host, fsize, framer = liblz4_frame(tile, 4, reps)
             f2 = torch.from_numpy(host).to(dev)
             tx = torch.from_numpy(tile).to(dev).repeat(reps)
             b2 = torch.empty(m, dtype=torch.uint8, device=dev)
@@ -344,8 +391,9 @@ def main():
             data = src[:m].cpu().numpy()
             hp = conduit.make_preferences(blockSizeID=7, blockMode=1)
             bound = L.lz4f_mi355x_compressFrameBound(m, ctypes.byref(hp))
-            out = {"what": "lz4f_mi355x_compressFrame / decompressFrame, 1 GiB of the stream, 4 MiB independent blocks, host buffers in and out; the link: PCIe Gen5 x16, "
-                           "%.0f GB/s spec, 53-54 GiB/s measured each way - a round trip moves the uncompressed bytes over it twice, so <= ~26 GiB/s per GPU whatever the kernels do" % PCIE_GBS}
+            out = {"what": "lz4f_mi355x_compressFrame / decompressFrame, 1 GiB of the stream, 4 MiB independent blocks, host buffers in and out, best of 5 after a warm-up pass; the link: PCIe Gen5 x16, "
+                           "%.0f GB/s spec, 53-54 GiB/s measured each way - a round trip moves the uncompressed bytes over it twice, so <= ~26 GiB/s per GPU whatever the kernels do" % PCIE_GBS,
+                   "calling_thread": where_am_i()}
 
             def ptr(a):
                 return a.ctypes.data_as(ctypes.c_void_p)
@@ -360,7 +408,7 @@ def main():
                 bc = bd = 1e9
                 good = True
                 try:
-                    for it in range(3):
+                    for it in range(6):                                  # (first pass: warm-up; best of 5)
                         t0_ = time.perf_counter()
                         rr = L.lz4f_mi355x_compressFrame(ptr(d_), bound, ptr(s_), m, ctypes.byref(hp))
                         t1_ = time.perf_counter()
@@ -381,6 +429,33 @@ def main():
             return out
         if want("host"): side["host_to_host"] = leg(host_legs)
 
+        def cck_cap():
+            # what a frame's content checksum (one XXH32 over the whole stream: one dependent chain) caps a stream at
+            L = _ffi.lib()
+            m = 256 << 20
+            p0 = conduit.make_preferences(blockSizeID=7, blockMode=1); p1 = conduit.make_preferences(blockSizeID=7, blockMode=1, contentChecksum=1)
+            f_ = torch.empty(eng.frame_bound(m, p1), dtype=torch.uint8, device=dev)
+            def dev_ms(pp):
+                best = 1e9
+                for _ in range(2):
+                    eng.compress_async(src[:m], f_, pp); eng.result(); best = min(best, eng.get_timing()["compress_total"])
+                return best
+            d0, d1 = dev_ms(p0), dev_ms(p1)
+            data = src[:m].cpu().numpy(); bound = L.lz4f_mi355x_compressFrameBound(m, ctypes.byref(p1)); dst_ = np.empty(bound, dtype=np.uint8)
+            def host_s(pp):
+                best = 1e9
+                for _ in range(3):
+                    t0_ = time.perf_counter(); rr = L.lz4f_mi355x_compressFrame(dst_.ctypes.data_as(ctypes.c_void_p), bound, data.ctypes.data_as(ctypes.c_void_p), m, ctypes.byref(pp)); t1_ = time.perf_counter()
+                    assert not L.LZ4F_isError(rr)
+                    best = min(best, t1_ - t0_)
+                return best
+            h0, h1 = host_s(p0), host_s(p1)
+            return {"what": "contentChecksum = 1 on 256 MiB of the stream: XXH32 of a whole stream is ONE chain of four accumulators (no way to combine partial states), so it caps the stream "
+                            "whatever the block kernels do: the device path runs it on one wave (k_xxh32_content), the host-pointer path on a host thread beside the transfers",
+                    "device_wave_GBs": round(m / max((d1 - d0) * 1e-3, 1e-9) / 1e9, 2), "device_compress_ms_without": round(d0, 3), "device_compress_ms_with": round(d1, 3),
+                    "host_call_GiBs_without": round(m / GIB / h0, 2), "host_call_GiBs_with": round(m / GIB / h1, 2)}
+        if want("cck"): side["content_checksum_cap"] = leg(cck_cap)
+
         def conduit_replay():
             import oracle
             m = 32 << 20
@@ -398,6 +473,54 @@ def main():
                     "gpu_library": {"compress_GiBs": round(g / (t1_ - t0_), 3), "decompress_GiBs": round(g / (t3_ - t2_), 3), "roundtrip_verified": good},
                     "cpu_1_thread": {"compress_GiBs": round(g / (t5_ - t4_), 3), "decompress_GiBs": round(g / (t7_ - t6_), 3), "kind": "port", "roundtrip_verified": rb == data}}
         if want("replay"): side["conduit_replay"] = leg(conduit_replay)
+
+    def multi_device_host(n_dev: int, m: int, logical: bool):
+        """ONE frame dealt over n_dev GPUs: lz4f_mi355x_use_devices(n_dev) + compressFrame / decompressFrame on page-locked host memory - the path a
+        Conduit user's stream takes, and the one that shards a single frame's blocks over the node (pipeline.hip: slabs dealt round-robin, a
+        stream per device, only sizes meet on the host)."""
+        L = _ffi.lib()
+        if logical: os.environ["LZ4F_MI355X_LOGICAL_DEVICES"] = str(n_dev)
+        hp = conduit.make_preferences(blockSizeID=7, blockMode=1)
+        bound = L.lz4f_mi355x_compressFrameBound(m, ctypes.byref(hp))
+        free = []
+        try:
+            rdev = L.lz4f_mi355x_use_devices(n_dev)
+            if L.LZ4F_isError(rdev): raise RuntimeError("use_devices(%d): %s" % (n_dev, L.LZ4F_getErrorName(rdev).decode()))
+            for x in (m, bound, m + 8):
+                p_ = L.lz4f_mi355x_host_alloc(x)
+                if not p_: raise MemoryError("page-locked allocation of %d bytes" % x)
+                free.append(p_)
+            s_, d_, b_ = [np.ctypeslib.as_array((ctypes.c_uint8 * x).from_address(p_)) for x, p_ in zip((m, bound, m + 8), free)]
+            tile = src[:min(m, 1 << 30)].cpu().numpy()
+            for a in range(0, m, tile.size): s_[a:a + tile.size] = tile[:min(tile.size, m - a)]
+            bc = bd = 1e9; good = True
+            for it in range(4):
+                t0_ = time.perf_counter()
+                rr = L.lz4f_mi355x_compressFrame(d_.ctypes.data_as(ctypes.c_void_p), bound, s_.ctypes.data_as(ctypes.c_void_p), m, ctypes.byref(hp))
+                t1_ = time.perf_counter()
+                if L.LZ4F_isError(rr): raise RuntimeError(L.LZ4F_getErrorName(rr).decode())
+                used = ctypes.c_size_t(0)
+                t2_ = time.perf_counter()
+                r2_ = L.lz4f_mi355x_decompressFrame(b_.ctypes.data_as(ctypes.c_void_p), m + 8, d_.ctypes.data_as(ctypes.c_void_p), rr, ctypes.byref(used))
+                t3_ = time.perf_counter()
+                if L.LZ4F_isError(r2_): raise RuntimeError(L.LZ4F_getErrorName(r2_).decode())
+                if it: bc = min(bc, t1_ - t0_); bd = min(bd, t3_ - t2_)
+            good = bool(r2_ == m and used.value == rr and np.array_equal(b_[:m], s_))
+            g = m / GIB
+            return {"what": "ONE LZ4 frame of %.0f GiB (4 MiB independent blocks) in page-locked host memory, its slabs dealt over %d %s device(s) by lz4f_mi355x_use_devices, "
+                            "compressFrame + decompressFrame host to host, best of 3 after a warm-up pass" % (g, n_dev, "LOGICAL (mapped onto the visible GPU: plumbing, not a measurement of N links)" if logical else "physical"),
+                    "devices": n_dev, "logical": logical, "compress_GiBs": round(g / bc, 2), "decompress_GiBs": round(g / bd, 2), "round_trip_GiBs": round(g / (bc + bd), 2),
+                    "roundtrip_verified": good, "calling_thread": where_am_i()}
+        finally:
+            for p_ in free: L.lz4f_mi355x_host_free(p_)
+            L.lz4f_mi355x_use_devices(1)
+            L.lz4f_mi355x_release_engines()
+            if logical: os.environ.pop("LZ4F_MI355X_LOGICAL_DEVICES", None)
+    if rank == 0 and not args.headline_only and want("multi"):
+        # N ranks: the one-frame host path over all N GPUs of the node (the other ranks idle at the closing barrier); one GPU: two logical devices
+        if world > 1 and not share: side["multi_device_host"] = leg(lambda: multi_device_host(world, 8 << 30, False))
+        elif world > 1: side["multi_device_host"] = leg(lambda: multi_device_host(world, 512 << 20, True))      # (LZ4F_BENCH_SHARE_GPU: a test switch)
+        else: side["multi_device_host"] = leg(lambda: multi_device_host(2, 2 << 30, True))
 
     if rank == 0:
         total_u = n * world * args.steps
@@ -450,6 +573,15 @@ def main():
         print(json.dumps(out))
     eng.close()
     if world > 1:
+        # (rank 0's one-frame leg drives every GPU of the node from its own process: the other ranks wait for it on the CPU - the
+        # rendezvous store - not in a collective that would spin on their GPUs meanwhile)
+        import datetime
+        try:
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0: store.set("lz4f_bench_rank0_done", "1")
+            else: store.wait(["lz4f_bench_rank0_done"], datetime.timedelta(minutes=15))
+        except Exception:      # noqa: BLE001
+            pass
         dist.barrier()
         dist.destroy_process_group()
     if not ok:

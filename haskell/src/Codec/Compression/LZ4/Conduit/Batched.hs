@@ -17,8 +17,8 @@ of blocks per call - through the same C ABI:
 * 'compressWithPreferences' - the reference's slice loop with the caller's 'Preferences';
 * 'compressBatched' - gathers @batchBytes@ of input in a page-locked buffer, then ONE
   @LZ4F_compressUpdate@ (a single call may create many blocks, @Conduit.hsc:326-333@);
-* 'decompressBatched' - gathers the stream and decodes frame by frame through
-  @lz4f_mi355x_decompressFrameTo@, which yields the output slab by slab.
+* 'decompressBatched' / 'decompressBatchedWith' - walks the size words over the incoming chunks and hands runs of whole blocks
+  to @lz4f_mi355x_fdec_blocks@ (bounded memory: one batch of input and the slabs in flight), which yields the output slab by slab.
 
 The C++ mirror of exactly these three drivers is @lz4_frame_conduit_amd/csrc/conduit.cpp@; it is what
 @tests/test_gpu_parity.py@ runs (@test_conduits_on_reference_test_inputs@, @test_batched_decoder_walks_whole_streams@).
@@ -29,7 +29,9 @@ module Codec.Compression.LZ4.Conduit.Batched
   ( compressWithPreferences
   , compressBatched
   , decompressBatched
+  , decompressBatchedWith
   , defaultBatchBytes
+  , defaultDecodeBatchBytes
   , appendBlockList
   ) where
 
@@ -51,7 +53,7 @@ import           Foreign.C.Types (CChar, CSize (..), CUInt (..))
 import           Foreign.Marshal.Alloc (alloca, allocaBytes, free, mallocBytes)
 import           Foreign.Marshal.Utils (copyBytes, new)
 import           Foreign.Ptr (FunPtr, Ptr, freeHaskellFunPtr, nullPtr, plusPtr)
-import           Foreign.Storable (peek)
+import           Foreign.Storable (peek, peekByteOff)
 import           UnliftIO.Exception (throwString)
 
 import           Codec.Compression.LZ4.Conduit (BlockSizeID (..), FrameInfo (..), Preferences (..))
@@ -71,10 +73,16 @@ foreign import ccall safe   "LZ4F_compressEnd"             c_compressEnd :: Ptr 
 -- page-locked host memory: the bulk path copies straight out of / into it (no staging copy)
 foreign import ccall safe   "lz4f_mi355x_host_alloc"       c_hostAlloc :: CSize -> IO (Ptr CChar)
 foreign import ccall safe   "lz4f_mi355x_host_free"        c_hostFree :: Ptr CChar -> IO ()
--- size_t lz4f_mi355x_decompressFrameTo(yield, user, src, srcSize, &consumed): one whole frame, output handed to `yield` in order
+-- the output of a bulk decode is handed to a callback, slab by slab, in order
 type YieldFn = Ptr () -> Ptr CChar -> CSize -> IO ()
-foreign import ccall safe   "lz4f_mi355x_decompressFrameTo" c_decompressFrameTo :: FunPtr YieldFn -> Ptr () -> Ptr CChar -> CSize -> Ptr CSize -> IO CSize
 foreign import ccall "wrapper" mkYieldFn :: YieldFn -> IO (FunPtr YieldFn)
+-- a frame decoded batch by batch (include/lz4f_mi355x.h: lz4f_mi355x_fdec_*): header once, runs of whole blocks, the closing words
+data Fdec
+foreign import ccall unsafe "LZ4F_headerSize"              c_headerSize :: Ptr CChar -> CSize -> IO CSize
+foreign import ccall safe   "lz4f_mi355x_fdec_create"      c_fdecCreate :: Ptr (Ptr Fdec) -> Ptr CChar -> CSize -> Ptr () -> IO CSize
+foreign import ccall safe   "lz4f_mi355x_fdec_blocks"      c_fdecBlocks :: Ptr Fdec -> FunPtr YieldFn -> Ptr () -> Ptr CChar -> CSize -> IO CSize
+foreign import ccall safe   "lz4f_mi355x_fdec_end"         c_fdecEnd :: Ptr Fdec -> Ptr CChar -> CSize -> IO CSize
+foreign import ccall safe   "lz4f_mi355x_fdec_free"        c_fdecFree :: Ptr Fdec -> IO ()
 -- the block list of a finished frame (include/lz4f_mi355x.h: host work only, no GPU)
 foreign import ccall unsafe "lz4f_mi355x_blockListSize"     c_blockListSize :: Ptr CChar -> CSize -> IO CSize
 foreign import ccall unsafe "lz4f_mi355x_appendBlockList"   c_appendBlockList :: Ptr CChar -> CSize -> CSize -> IO CSize
@@ -196,55 +204,138 @@ compressGathering pinned batch prefs = bracketP acquire release run
       emit =<< liftIO (checkLz4 (c_compressEnd (csCtx s) (csOut s) (csOutSize s) nullPtr))
 
 
-data Handoff = Chunk !ByteString | Done !CSize !CSize      -- result of the call, bytes of input it consumed
+data Handoff = Chunk !ByteString | Done !CSize      -- a piece of output; the C call's result
 
 
--- | Decodes a stream of LZ4 frames through the bulk path: per frame the library walks the size words on the host, keeps slabs of
--- blocks in flight on the GPU(s) and hands the output over slab by slab (at most one slab waits in the hand-off).  Unlike the
--- reference's 'decompress' (which stops at the first EndMark and cannot read headers with a dictID) this decodes every frame of
--- the stream, skips skippable frames and accepts every header the format allows - what calling @LZ4F_decompress@ in a loop does.
--- The input is gathered first: a frame's blocks cannot be found before its size words are there.
--- Build with @-threaded@: the C call runs beside the conduit and calls back into Haskell.
+-- | 256 MiB of whole blocks per @lz4f_mi355x_fdec_blocks@ call: four slabs of the library's host pipeline in flight.
+defaultDecodeBatchBytes :: Int
+defaultDecodeBatchBytes = 256 * 1024 * 1024
+
+
+-- | 'decompressBatchedWith' 'defaultDecodeBatchBytes'.
 decompressBatched :: forall m . (MonadUnliftIO m, MonadResource m) => ConduitT ByteString ByteString m ()
-decompressBatched = do
-  stream <- BS.concat <$> gatherAll
-  when (BS.length stream < 5) $
-    throwString ("lz4 decompress error: not enough bytes for header; expected 5, got " ++ show (BS.length stream))
-  frames stream
+decompressBatched = decompressBatchedWith defaultDecodeBatchBytes
+
+
+-- | Decodes a stream of LZ4 frames through the bulk path in BOUNDED memory.  The conduit walks the size words over the chunks as
+-- they arrive (a 4-byte read per block), cuts runs of whole blocks - @batchBytes@ of them at a time - and hands each run to
+-- @lz4f_mi355x_fdec_blocks@, which keeps slabs of blocks in flight on the GPU(s) and hands the output back slab by slab, in
+-- order.  What is held: one batch of input, the chunk being cut, the slabs in flight - whatever the stream's length (the
+-- reference's 'decompress' holds one @max(hint, 16 KiB)@ buffer, @Conduit.hsc:634-659@; an earlier version of this conduit gathered
+-- the whole stream first).  Linked frames carry their 64 KiB of history from run to run inside the decoder object; content
+-- checksum and contentSize are verified over all runs by @lz4f_mi355x_fdec_end@.
+-- Unlike the reference's 'decompress' (which stops at the first EndMark and cannot read headers with a dictID) this decodes every
+-- frame of the stream, skips skippable frames and accepts every header the format allows - what calling @LZ4F_decompress@ in a
+-- loop does.  Build with @-threaded@: the C call runs beside the conduit and calls back into Haskell.
+decompressBatchedWith :: forall m . (MonadUnliftIO m, MonadResource m) => Int -> ConduitT ByteString ByteString m ()
+decompressBatchedWith batchBytes0 = go BS.empty 0 False
   where
-    gatherAll = await >>= \case
-      Nothing -> return []
-      Just bs -> (bs :) <$> gatherAll
+    batchBytes = max (1024 * 1024) batchBytes0
 
     le32 :: ByteString -> Int -> Word32
     le32 b i = fromIntegral (BS.index b i) .|. (fromIntegral (BS.index b (i + 1)) `shiftL` 8)
            .|. (fromIntegral (BS.index b (i + 2)) `shiftL` 16) .|. (fromIntegral (BS.index b (i + 3)) `shiftL` 24)
 
-    frames :: ByteString -> ConduitT ByteString ByteString m ()
-    frames rest
-      | BS.null rest = return ()
-      | BS.length rest < 4 = throwString "lz4frame error: \"ERROR_frameHeader_incomplete\""
-      | le32 rest 0 .&. 0xFFFFFFF0 == 0x184D2A50 = do                       -- skippable frame: magic, u32 size, payload
-          when (BS.length rest < 8) $ throwString "lz4frame error: \"ERROR_frameHeader_incomplete\""
-          let sz = fromIntegral (le32 rest 4) :: Int
-          when (BS.length rest - 8 < sz) $ throwString "lz4 decompress error: stream ended before EndMark"
-          frames (BS.drop (8 + sz) rest)
-      | otherwise = do
-          used <- oneFrame rest
-          frames (BS.drop used rest)
+    -- at least n bytes of input in hand (Nothing: the stream ended first); what came in addition is counted
+    ensure :: Int -> ByteString -> Int -> ConduitT ByteString ByteString m (Maybe ByteString, Int)
+    ensure n have seen
+      | BS.length have >= n = return (Just have, seen)
+      | otherwise = await >>= \case
+          Nothing -> return (Nothing, seen)
+          Just bs -> ensure n (if BS.null have then bs else have <> bs) (seen + BS.length bs)
 
-    -- One frame.  The C call runs on its own thread and hands every piece of output over through a one-place MVar, so the
-    -- conduit yields while the next slab is being decoded and nothing piles up.  If the conduit is abandoned downstream, the
-    -- cancel flag makes the callback drop what is left, and the call runs to its end without blocking.
-    oneFrame :: ByteString -> ConduitT ByteString ByteString m Int
-    oneFrame frame = bracketP setup teardown $ \(box, _, finished, _) ->
+    endedEarly :: ConduitT ByteString ByteString m a
+    endedEarly = throwString "lz4 decompress error: stream ended before EndMark"
+
+    -- between frames: pending input, bytes seen so far, whether any frame was seen
+    go :: ByteString -> Int -> Bool -> ConduitT ByteString ByteString m ()
+    go pend seen anyFrame = do
+      (m1, seen1) <- ensure 1 pend seen
+      case m1 of
+        Nothing
+          | anyFrame  -> return ()
+          | otherwise -> throwString ("lz4 decompress error: not enough bytes for header; expected 5, got " ++ show seen1)
+        Just p1 -> do
+          (m4, seen4) <- ensure 4 p1 seen1
+          case m4 of
+            Nothing
+              | not anyFrame && seen4 < 5 -> throwString ("lz4 decompress error: not enough bytes for header; expected 5, got " ++ show seen4)
+              | otherwise -> throwString "lz4frame error: \"ERROR_frameHeader_incomplete\""
+            Just p4
+              | le32 p4 0 .&. 0xFFFFFFF0 == 0x184D2A50 -> do              -- skippable frame: dropped as it arrives
+                  (m8, seen8) <- ensure 8 p4 seen4
+                  p8 <- maybe (throwString "lz4frame error: \"ERROR_frameHeader_incomplete\"") return m8
+                  (rest, seen') <- skipBytes (fromIntegral (le32 p8 4)) (BS.drop 8 p8) seen8
+                  go rest seen' True
+              | otherwise -> do
+                  (rest, seen') <- oneFrame p4 seen4
+                  go rest seen' True
+
+    skipBytes :: Int -> ByteString -> Int -> ConduitT ByteString ByteString m (ByteString, Int)
+    skipBytes n have seen
+      | BS.length have >= n = return (BS.drop n have, seen)
+      | otherwise = await >>= \case
+          Nothing -> endedEarly
+          Just bs -> skipBytes (n - BS.length have) bs (seen + BS.length bs)
+
+    -- One frame: header -> decoder object; runs of whole blocks; the closing words.
+    oneFrame :: ByteString -> Int -> ConduitT ByteString ByteString m (ByteString, Int)
+    oneFrame p0 seen0 = do
+      (m7, seen7) <- ensure 7 p0 seen0
+      p7 <- case m7 of
+        Just x -> return x
+        Nothing | seen7 < 5 -> throwString ("lz4 decompress error: not enough bytes for header; expected 5, got " ++ show seen7)
+                | otherwise -> throwString "lz4frame error: \"ERROR_frameHeader_incomplete\""
+      hs <- liftIO $ unsafeUseAsCStringLen p7 $ \(p, n) -> checkLz4 (c_headerSize p (fromIntegral n))
+      (mh, seenh) <- ensure (fromIntegral hs) p7 seen7
+      ph <- maybe (throwString "lz4frame error: \"ERROR_frameHeader_incomplete\"") return mh
+      bracketP (openDec (BS.take (fromIntegral hs) ph)) (\(d, _, _, _) -> c_fdecFree d) $ \(dec, bck, cck, maxBlock) -> do
+        let crc = if bck then 4 else 0
+            tailLen = if cck then 8 else 4
+            -- `run` bytes of whole blocks lie at the front of `have`
+            blocks have seen run = do
+              (mw, seenw) <- ensure (run + 4) have seen
+              hw <- maybe endedEarly return mw
+              let w = le32 hw run
+                  csz = fromIntegral (w .&. 0x7FFFFFFF) :: Int
+              if w == 0
+                then do
+                  when (run > 0) $ runBlocks dec (BS.take run hw)
+                  (mt, seent) <- ensure (run + tailLen) hw seenw
+                  ht <- maybe endedEarly return mt
+                  _ <- liftIO $ unsafeUseAsCStringLen (BS.take tailLen (BS.drop run ht)) $ \(p, n) -> checkLz4 (c_fdecEnd dec p (fromIntegral n))
+                  return (BS.drop (run + tailLen) ht, seent)
+                else do
+                  when (csz > maxBlock) $ throwString "lz4frame error: \"ERROR_maxBlockSize_invalid\""
+                  let step = 4 + csz + crc
+                  (mb, seenb) <- ensure (run + step) hw seenw
+                  hb <- maybe endedEarly return mb
+                  if run + step >= batchBytes
+                    then runBlocks dec (BS.take (run + step) hb) >> blocks (BS.drop (run + step) hb) seenb 0
+                    else blocks hb seenb (run + step)
+        blocks (BS.drop (fromIntegral hs) ph) seenh 0
+
+    openDec :: ByteString -> IO (Ptr Fdec, Bool, Bool, Int)
+    openDec hdr = unsafeUseAsCStringLen hdr $ \(p, n) -> alloca $ \pp -> allocaBytes 32 $ \fi -> do
+      _ <- checkLz4 (c_fdecCreate pp p (fromIntegral n) fi)
+      d <- peek pp
+      -- LZ4F_frameInfo_t (CTypes.hsc:155-232): blockSizeID u32 @0, contentChecksumFlag u32 @8, blockChecksumFlag u32 @28
+      bsid <- peekByteOff fi 0 :: IO Word32
+      cckF <- peekByteOff fi 8 :: IO Word32
+      bckF <- peekByteOff fi 28 :: IO Word32
+      let maxBlock = case bsid of { 5 -> 256 * 1024; 6 -> 1024 * 1024; 7 -> 4 * 1024 * 1024; _ -> 64 * 1024 }
+      return (d, bckF /= 0, cckF /= 0, maxBlock)
+
+    -- One run of whole blocks.  The C call runs on its own thread and hands every piece of output over through a one-place MVar,
+    -- so the conduit yields while the next slab is being decoded and nothing piles up.  If the conduit is abandoned downstream,
+    -- the cancel flag makes the callback drop what is left, and the call runs to its end without blocking.
+    runBlocks :: Ptr Fdec -> ByteString -> ConduitT ByteString ByteString m ()
+    runBlocks dec run = bracketP setup teardown $ \(box, _, finished, _) ->
       let loop = liftIO (takeMVar box) >>= \case
             Chunk bs -> yield bs >> loop
-            Done r used -> do
+            Done r -> do
               liftIO (writeIORef finished True)
               void (liftIO (checkLz4 (return r)))                           -- same exception text as the reference's
-              when (used == 0) $ throwString "lz4 decompress error: stream ended before EndMark"
-              return (fromIntegral used)
       in loop
       where
         setup = do
@@ -254,18 +345,17 @@ decompressBatched = do
           cb <- mkYieldFn $ \_ dat n -> do
             gone <- readIORef cancelled
             unless gone $ putMVar box . Chunk =<< packCStringLen (dat, fromIntegral n)
-          _ <- forkIO $ unsafeUseAsCStringLen frame $ \(p, n) -> alloca $ \usedPtr -> do
-            r <- c_decompressFrameTo cb nullPtr p (fromIntegral n) usedPtr
-            used <- peek usedPtr
-            putMVar box (Done r used)
+          _ <- forkIO $ unsafeUseAsCStringLen run $ \(p, n) -> do
+            r <- c_fdecBlocks dec cb nullPtr p (fromIntegral n)
+            putMVar box (Done r)
           return (box, cancelled, finished, cb)
         teardown (box, cancelled, finished, cb) = do
           writeIORef cancelled True
           -- abandoned before the end: take what the callback is still handing over until the call says it is done;
           -- only then may the callback be freed
           let drain = takeMVar box >>= \case
-                Done _ _ -> return ()
-                Chunk _  -> drain
+                Done _  -> return ()
+                Chunk _ -> drain
           seen <- readIORef finished
           unless seen drain
           freeHaskellFunPtr cb

@@ -191,6 +191,21 @@ LZ4F_MI355X_API size_t lz4f_mi355x_decompressFrame(void* dst, size_t dstCapacity
 typedef void (*lz4f_mi355x_yield_fn)(void* user, const void* data, size_t size);
 LZ4F_MI355X_API size_t lz4f_mi355x_decompressFrameTo(lz4f_mi355x_yield_fn yield, void* user, const void* src, size_t srcSize,
                                                      size_t* srcConsumed);
+/* A frame decoded BATCH BY BATCH, for callers that receive a stream and must not hold all of it (the bounded decompressBatched conduit;
+ * the reference's `decompress` holds one max(hint, 16 KiB) buffer, Conduit.hsc:634-659).  The caller walks the size words over what arrives:
+ *   fdec_create   parses a complete frame header (LZ4F_headerSize says how many bytes that is); returns its size, fills *info (may be NULL)
+ *   fdec_blocks   a run of WHOLE blocks - [u32 size word | payload | u32 checksum if the header says so]* - is decoded through the bulk path
+ *                 (slabs of blocks in flight over the devices lz4f_mi355x_use_devices named) and handed to `yield` in order; returns the decoded
+ *                 bytes.  Linked frames: the last 64 KiB handed over are kept inside for the next run.  Memory: the run + the slabs in flight.
+ *   fdec_end      `tail` = the EndMark and, if the header asks for one, the content checksum behind it: verifies contentSize and the checksum
+ *                 over everything the runs produced; returns the bytes of tail consumed (4 or 8)
+ *   fdec_free     always, also after an error */
+typedef struct lz4f_mi355x_fdec lz4f_mi355x_fdec;
+LZ4F_MI355X_API size_t lz4f_mi355x_fdec_create(lz4f_mi355x_fdec** out, const void* header, size_t headerBytes, LZ4F_frameInfo_t* info);
+LZ4F_MI355X_API size_t lz4f_mi355x_fdec_blocks(lz4f_mi355x_fdec* d, lz4f_mi355x_yield_fn yield, void* user, const void* blocks, size_t blocksBytes);
+LZ4F_MI355X_API size_t lz4f_mi355x_fdec_end(lz4f_mi355x_fdec* d, const void* tail, size_t tailBytes);
+LZ4F_MI355X_API void   lz4f_mi355x_fdec_free(lz4f_mi355x_fdec* d);
+
 /* How many GPUs the bulk calls above deal their slabs over (round-robin, starting at the calling thread's device; default 1).
  * Blocks of an independent-block frame need nothing from each other: no collective, the host puts the slabs' output in order.
  * Process-wide.  count must be <= the visible devices (test switch: with LZ4F_MI355X_LOGICAL_DEVICES=n in the environment up to
@@ -360,6 +375,8 @@ LZ4F_MI355X_API int lz4f_mi355x_conduit_compress_batched(size_t batchBytes, cons
 LZ4F_MI355X_API int lz4f_mi355x_conduit_compress_batched_listed(size_t batchBytes, const LZ4F_preferences_t* prefs,
                                                  lz4f_mi355x_await_fn await, lz4f_mi355x_yield_fn yield, void* user,
                                                  char* errbuf, size_t errcap);
+LZ4F_MI355X_API int lz4f_mi355x_conduit_decompress_batched_bounded(size_t batchBytes, lz4f_mi355x_await_fn await, lz4f_mi355x_yield_fn yield, void* user,
+                                                                  char* errbuf, size_t errcap);
 LZ4F_MI355X_API int lz4f_mi355x_conduit_decompress_batched(lz4f_mi355x_await_fn await, lz4f_mi355x_yield_fn yield, void* user,
                                                  char* errbuf, size_t errcap);
 

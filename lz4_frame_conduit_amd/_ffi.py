@@ -90,6 +90,10 @@ _SIGS = {
     "lz4f_mi355x_conduit_compress_batched_listed": (ctypes.c_int, [c_size_t, PP, AWAIT_FN, YIELD_FN, c_void_p, ctypes.c_char_p, c_size_t]),
     "lz4f_mi355x_blockListSize": (c_size_t, [c_void_p, c_size_t]), "lz4f_mi355x_appendBlockList": (c_size_t, [c_void_p, c_size_t, c_size_t]),
     "lz4f_mi355x_conduit_decompress_batched": (ctypes.c_int, [AWAIT_FN, YIELD_FN, c_void_p, ctypes.c_char_p, c_size_t]),
+    "lz4f_mi355x_conduit_decompress_batched_bounded": (ctypes.c_int, [c_size_t, AWAIT_FN, YIELD_FN, c_void_p, ctypes.c_char_p, c_size_t]),
+    "lz4f_mi355x_fdec_create": (c_size_t, [ctypes.POINTER(c_void_p), c_void_p, c_size_t, ctypes.POINTER(FrameInfo)]),
+    "lz4f_mi355x_fdec_blocks": (c_size_t, [c_void_p, YIELD_FN, c_void_p, c_void_p, c_size_t]),
+    "lz4f_mi355x_fdec_end": (c_size_t, [c_void_p, c_void_p, c_size_t]), "lz4f_mi355x_fdec_free": (None, [c_void_p]),
 }
 DECLARED_SYMBOLS = tuple(_SIGS)
 

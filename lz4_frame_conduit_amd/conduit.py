@@ -114,5 +114,8 @@ def appendBlockList(frame: bytes) -> bytes:
     return buf.raw[:r]
 
 
-def decompressBatched(chunks: Iterable[bytes]) -> List[bytes]:
-    return _run("lz4f_mi355x_conduit_decompress_batched", chunks)
+def decompressBatched(chunks: Iterable[bytes], batchBytes: Optional[int] = None) -> List[bytes]:
+    """Every frame of the stream through the bulk path in bounded memory: runs of whole blocks, `batchBytes` (default 256 MiB) at a time."""
+    if batchBytes is None:
+        return _run("lz4f_mi355x_conduit_decompress_batched", chunks)
+    return _run("lz4f_mi355x_conduit_decompress_batched_bounded", chunks, batchBytes)

@@ -276,51 +276,88 @@ void compressBatched(size_t batchBytes, const LZ4F_preferences_t* prefsIn, const
     }
 }
 
-// decompressBatched: gathers the stream and decodes each frame's blocks through the bulk path
-// (lz4f_mi355x_decompressFrameTo: host walk of the size words, slabs of blocks in flight), yielding slab by slab - what is held
-// in memory is bounded by the slabs in flight, whatever block size the header names and however short the blocks are.
-void decompressBatched(const Await& await, const Yield& yield)
+// decompressBatched: decodes every frame of the stream through the bulk path, in BOUNDED memory.  The conduit walks the size words over
+// the chunks as they arrive (a 4-byte read per block) and hands runs of whole blocks - `batchBytes` of them at a time - to
+// lz4f_mi355x_fdec_blocks (slabs of blocks in flight on the GPU(s), output yielded slab by slab, in order); what is held is one batch of
+// input, the chunk being cut and the slabs in flight, whatever the stream's length (the reference's `decompress` holds one
+// max(hint, 16 KiB) buffer, Conduit.hsc:634-659; rounds 2-3 gathered the whole stream first).
+// Unlike `decompress` (which mirrors the reference and stops after the first frame, Appendix C quirk 3, and cannot read dictID
+// headers, quirk 2), this walks the whole stream the way LZ4F_decompress called in a loop would: skippable frames are skipped,
+// concatenated frames are all decoded, any header the format allows is accepted.
+void decompressBatched(const Await& await, const Yield& yield, size_t batchBytes)
 {
-    std::vector<uint8_t> frame;
-    Slice bs;
-    while (await(bs)) frame.insert(frame.end(), bs.data, bs.data + bs.size);
-    if (frame.size() < 5)
-        throw std::runtime_error("lz4 decompress error: not enough bytes for header; expected 5, got " + std::to_string(frame.size()));
-    // Unlike `decompress` (which mirrors the reference and stops after the first frame, Appendix C quirk 3, and cannot read
-    // dictID headers, quirk 2), this walks the whole stream the way LZ4F_decompress called in a loop would: skippable
-    // frames are skipped, concatenated frames are all decoded, any header the format allows is accepted.
-    auto le32 = [&](size_t at) { return (uint32_t)frame[at] | ((uint32_t)frame[at + 1] << 8) | ((uint32_t)frame[at + 2] << 16) | ((uint32_t)frame[at + 3] << 24); };
-    size_t at = 0;
+    if (batchBytes < ((size_t)1 << 20)) batchBytes = (size_t)1 << 20;
+    std::vector<uint8_t> buf;                                              // bytes received and not yet decoded: [off, buf.size())
+    size_t off = 0, total_in = 0;
+    bool eof = false;
+    // at least `want` bytes behind `off` (false: the stream ended first)
+    auto ensure = [&](size_t want) -> bool {
+        while (buf.size() - off < want && !eof) {
+            Slice bs;
+            if (!await(bs)) { eof = true; break; }
+            if (off && off == buf.size()) { buf.clear(); off = 0; }
+            else if (off > (buf.size() >> 1) && off > (1u << 16)) { buf.erase(buf.begin(), buf.begin() + (ptrdiff_t)off); off = 0; }      // (keep the buffer from creeping: what is decoded goes)
+            buf.insert(buf.end(), bs.data, bs.data + bs.size);
+            total_in += bs.size;
+        }
+        return buf.size() - off >= want;
+    };
+    auto le32 = [&](size_t at) { const uint8_t* q = buf.data() + off + at; return (uint32_t)q[0] | ((uint32_t)q[1] << 8) | ((uint32_t)q[2] << 16) | ((uint32_t)q[3] << 24); };
     struct Ctx { const Yield* y; } ctx{&yield};
     auto to_yield = [](void* user, const void* data, size_t size) { (*((Ctx*)user)->y)(Slice{(const uint8_t*)data, size}); };
-    while (at < frame.size()) {
-        const uint8_t* f = frame.data() + at;
-        const size_t left = frame.size() - at;
-        if (left < 4) handleLz4Error(make_err(LZ4F_ERROR_frameHeader_incomplete));
-        const uint32_t magic = le32(at);
-        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {                        // skippable: magic, u32 size, payload
-            if (left < 8) handleLz4Error(make_err(LZ4F_ERROR_frameHeader_incomplete));
-            const size_t sz = le32(at + 4);
-            if (left - 8 < sz) throw std::runtime_error("lz4 decompress error: stream ended before EndMark");
-            at += 8 + sz;
+    struct Dec { lz4f_mi355x_fdec* d = nullptr; ~Dec() { lz4f_mi355x_fdec_free(d); } };
+    bool any = false;
+    for (;;) {
+        if (!ensure(1)) break;                                               // the stream ends between frames
+        if (!ensure(4)) {
+            if (!any && total_in < 5) throw std::runtime_error("lz4 decompress error: not enough bytes for header; expected 5, got " + std::to_string(total_in));
+            handleLz4Error(make_err(LZ4F_ERROR_frameHeader_incomplete));
+        }
+        any = true;
+        const uint32_t magic = le32(0);
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {                        // skippable: magic, u32 size, payload - dropped as it arrives
+            if (!ensure(8)) handleLz4Error(make_err(LZ4F_ERROR_frameHeader_incomplete));
+            size_t sz = le32(4);
+            off += 8;
+            while (sz) {
+                if (!ensure(1)) throw std::runtime_error("lz4 decompress error: stream ended before EndMark");
+                const size_t take = std::min(sz, buf.size() - off);
+                off += take; sz -= take;
+            }
             continue;
         }
-        ParsedHeader ph;
-        handleLz4Error(parse_frame_header(f, left, &ph));                  // frameType_unknown for anything else
-        // the frame must be complete (the reference's protocol error for a stream that ends early)
-        size_t pos = ph.header_size;
-        for (;;) {
-            if (left - pos < 4) throw std::runtime_error("lz4 decompress error: stream ended before EndMark");
-            const uint32_t w = le32(at + pos);
-            if (w == 0) break;
-            const size_t step = 4 + (size_t)(w & 0x7FFFFFFFu) + (ph.info.blockChecksumFlag ? 4 : 0);
-            if (left - pos < step) throw std::runtime_error("lz4 decompress error: stream ended before EndMark");
-            pos += step;
+        if (!ensure(7)) {
+            if (total_in < 5) throw std::runtime_error("lz4 decompress error: not enough bytes for header; expected 5, got " + std::to_string(total_in));
+            handleLz4Error(make_err(LZ4F_ERROR_frameHeader_incomplete));
         }
-        size_t used = 0;
-        handleLz4Error(lz4f_mi355x_decompressFrameTo(to_yield, &ctx, f, left, &used));
-        at += used;
+        const size_t hs = LZ4F_headerSize(buf.data() + off, buf.size() - off);
+        handleLz4Error(hs);                                                // frameType_unknown for anything that is no frame
+        if (!ensure(hs)) handleLz4Error(make_err(LZ4F_ERROR_frameHeader_incomplete));
+        Dec dec; LZ4F_frameInfo_t fi;
+        handleLz4Error(lz4f_mi355x_fdec_create(&dec.d, buf.data() + off, hs, &fi));
+        off += hs;
+        const size_t crc = fi.blockChecksumFlag ? 4 : 0;
+        const size_t max_block = block_size_of(fi.blockSizeID);
+        // runs of whole blocks
+        size_t run = 0;                                                    // bytes of whole blocks behind `off`
+        for (;;) {
+            if (!ensure(run + 4)) throw std::runtime_error("lz4 decompress error: stream ended before EndMark");
+            const uint32_t w = le32(run);
+            if (w == 0) break;
+            const size_t csz = w & 0x7FFFFFFFu;
+            if (csz > max_block) handleLz4Error(make_err(LZ4F_ERROR_maxBlockSize_invalid));
+            const size_t step = 4 + csz + crc;
+            if (!ensure(run + step)) throw std::runtime_error("lz4 decompress error: stream ended before EndMark");
+            run += step;
+            if (run >= batchBytes) { handleLz4Error(lz4f_mi355x_fdec_blocks(dec.d, to_yield, &ctx, buf.data() + off, run)); off += run; run = 0; }
+        }
+        if (run) { handleLz4Error(lz4f_mi355x_fdec_blocks(dec.d, to_yield, &ctx, buf.data() + off, run)); off += run; }
+        const size_t tail = 4 + (fi.contentChecksumFlag ? 4 : 0);
+        if (!ensure(tail)) throw std::runtime_error("lz4 decompress error: stream ended before EndMark");
+        handleLz4Error(lz4f_mi355x_fdec_end(dec.d, buf.data() + off, tail));
+        off += tail;
     }
+    if (!any) throw std::runtime_error("lz4 decompress error: not enough bytes for header; expected 5, got " + std::to_string(total_in));
 }
 
 }  // namespace conduit
@@ -379,6 +416,10 @@ int lz4f_mi355x_conduit_compress_batched_listed(size_t batchBytes, const LZ4F_pr
 }
 int lz4f_mi355x_conduit_decompress_batched(lz4f_mi355x_await_fn a, lz4f_mi355x_yield_fn y, void* user, char* errbuf, size_t errcap)
 {
-    return guarded(errbuf, errcap, [&] { decompressBatched(wrap_await(a, user), wrap_yield(y, user)); });
+    return guarded(errbuf, errcap, [&] { decompressBatched(wrap_await(a, user), wrap_yield(y, user), (size_t)256 << 20); });
+}
+int lz4f_mi355x_conduit_decompress_batched_bounded(size_t batchBytes, lz4f_mi355x_await_fn a, lz4f_mi355x_yield_fn y, void* user, char* errbuf, size_t errcap)
+{
+    return guarded(errbuf, errcap, [&] { decompressBatched(wrap_await(a, user), wrap_yield(y, user), batchBytes); });
 }
 }

@@ -25,7 +25,7 @@ void decompress(const Await&, const Yield&);                                    
 // additions: preferences as a parameter, and batched drivers for the GPU
 void compressWithPreferences(const LZ4F_preferences_t& prefs, const Await&, const Yield&);
 void compressBatched(size_t batchBytes, const LZ4F_preferences_t* prefs, const Await&, const Yield&, bool blockList = false);
-void decompressBatched(const Await&, const Yield&);
+void decompressBatched(const Await&, const Yield&, size_t batchBytes = (size_t)256 << 20);     // bounded memory: a batch of whole blocks at a time
 
 }  // namespace conduit
 }  // namespace lz4f

@@ -165,8 +165,10 @@ int    logical_devices();             // visible devices, or LZ4F_MI355X_LOGICAL
 // hist_before: valid input bytes in front of src (a linked frame's blocks reach 64 KiB back)
 size_t pipe_compress_blocks(const uint8_t* src, size_t n, uint32_t block_size, bool linked, bool bck, uint8_t* dst, size_t cap, size_t* written,
                             size_t hist_before = 0);
+// what a frame decoded batch by batch carries from one batch of blocks to the next (pipeline.hip)
+struct FrameCarry { Xxh32State cck; uint64_t out_total = 0; std::vector<uint8_t> hist; FrameCarry() { cck.reset(0); } };
 size_t pipe_decompress_frame(const uint8_t* frame, size_t n, const ParsedHeader& ph, uint8_t* flat, size_t flat_cap,
-                             const std::function<void(const uint8_t*, size_t)>* sink, size_t* decoded, size_t* consumed);
+                             const std::function<void(const uint8_t*, size_t)>* sink, size_t* decoded, size_t* consumed, FrameCarry* carry = nullptr);
 uint32_t pick_chunk_size(uint32_t block_size);
 // The block-list trailer (frame_dev.cuh: the trailer) made on the host, for frames the host paths assemble or are handed:
 // `at` = where every block's size word is in the frame.  host_trailer_size: the bytes it takes behind a frame of frame_size bytes

@@ -839,6 +839,46 @@ size_t lz4f_mi355x_decompressFrameTo(lz4f_mi355x_yield_fn yield, void* user, con
     return decompress_frame_common(nullptr, 0, src, srcSize, srcConsumed, &sink);
 }
 
+// ---- a frame decoded batch by batch (bounded memory): header once, runs of whole blocks as they arrive, the closing words at the end ----
+struct lz4f_mi355x_fdec { ParsedHeader ph; FrameCarry carry; bool ended = false; };
+
+size_t lz4f_mi355x_fdec_create(lz4f_mi355x_fdec** out, const void* header, size_t n, LZ4F_frameInfo_t* info)
+{
+    if (!out || !header) return make_err(LZ4F_ERROR_GENERIC);
+    *out = nullptr;
+    lz4f_mi355x_fdec* d = nullptr;
+    try { d = new lz4f_mi355x_fdec(); } catch (...) { return make_err(LZ4F_ERROR_allocation_failed); }
+    const size_t hs = parse_frame_header((const uint8_t*)header, n, &d->ph);
+    if (is_err(hs)) { delete d; return hs; }
+    if (info) *info = d->ph.info;
+    *out = d;
+    return d->ph.header_size;
+}
+size_t lz4f_mi355x_fdec_blocks(lz4f_mi355x_fdec* d, lz4f_mi355x_yield_fn yield, void* user, const void* blocks, size_t n)
+{
+    if (!d || !yield || d->ended) return make_err(LZ4F_ERROR_GENERIC);
+    if (n == 0) return 0;
+    const std::function<void(const uint8_t*, size_t)> sink = [&](const uint8_t* p, size_t k) { yield(user, p, k); };
+    size_t decoded = 0, consumed = 0;
+    const size_t r = pipe_decompress_frame((const uint8_t*)blocks, n, d->ph, nullptr, 0, &sink, &decoded, &consumed, &d->carry);
+    if (is_err(r)) return r;
+    if (consumed != n) { set_last_error("fdec_blocks: the batch is not a run of whole blocks (%zu of %zu bytes)", consumed, n); return make_err(LZ4F_ERROR_GENERIC); }
+    return decoded;
+}
+size_t lz4f_mi355x_fdec_end(lz4f_mi355x_fdec* d, const void* tail, size_t n)
+{
+    if (!d || d->ended) return make_err(LZ4F_ERROR_GENERIC);
+    const uint8_t* t = (const uint8_t*)tail;
+    const size_t need = 4 + (d->ph.info.contentChecksumFlag ? 4 : 0);
+    if (!t || n < need) return make_err(LZ4F_ERROR_frameHeader_incomplete);
+    if (le32(t) != 0) return make_err(LZ4F_ERROR_GENERIC);                        // not an EndMark
+    d->ended = true;
+    if (d->ph.info.contentSize && d->ph.info.contentSize != d->carry.out_total) return make_err(LZ4F_ERROR_frameSize_wrong);
+    if (d->ph.info.contentChecksumFlag && le32(t + 4) != d->carry.cck.digest()) return make_err(LZ4F_ERROR_contentChecksum_invalid);
+    return need;
+}
+void lz4f_mi355x_fdec_free(lz4f_mi355x_fdec* d) { delete d; }
+
 size_t lz4f_mi355x_use_devices(int count)
 {
     const int have = logical_devices();       // (the visible ones; more only under the test switch LZ4F_MI355X_LOGICAL_DEVICES)

@@ -136,8 +136,12 @@ size_t pipe_compress_blocks(const uint8_t* src, size_t n, uint32_t block_size, b
 // ---- decompress: a whole frame (host) -> `sink` (slab by slab, in order) ------------------------------------------------
 // sink(data, size, pinned_hint): the decoded bytes of the next slab; when `flat` is given the slabs are written there
 // instead (at their final offsets, straight from the device when it is page-locked) and sink is not called.
+// carry != nullptr: [s, s + n) is a RUN OF WHOLE BLOCKS of a frame whose header was `ph` (no header in front; an EndMark, if the run
+// holds one, ends the walk) - what the bounded batched decoder hands over batch by batch (frame_host.cpp: lz4f_mi355x_fdec_*).  The
+// frame-level state lives in `carry` between the calls: the content checksum's running state, the output so far, and - linked frames -
+// the last 64 KiB handed over, which the next batch's first slab decodes against.  The frame's closing checks are the caller's then.
 size_t pipe_decompress_frame(const uint8_t* s, size_t n, const ParsedHeader& ph, uint8_t* flat, size_t flat_cap,
-                             const std::function<void(const uint8_t*, size_t)>* sink, size_t* decoded, size_t* consumed)
+                             const std::function<void(const uint8_t*, size_t)>* sink, size_t* decoded, size_t* consumed, FrameCarry* carry)
 {
     const size_t SLAB_SRC = (size_t)64 << 20, SLAB_DST = (size_t)192 << 20;
     const size_t crc = ph.info.blockChecksumFlag ? 4 : 0;
@@ -147,11 +151,13 @@ size_t pipe_decompress_frame(const uint8_t* s, size_t n, const ParsedHeader& ph,
     struct SlabD { size_t src_at, src_len, first, count; };
     std::vector<lz4f_mi355x_block> entries;
     std::vector<SlabD> slabs;
-    size_t pos = ph.header_size;
+    size_t pos = carry ? 0 : ph.header_size;
+    bool endmark = false;
     for (;;) {
+        if (carry && pos == n) break;                           // (a batch ends with its last whole block)
         if (n - pos < 4) return make_err(LZ4F_ERROR_frameHeader_incomplete);
         const uint32_t w = rd32(pos);
-        if (w == 0) break;
+        if (w == 0) { endmark = true; break; }
         const size_t csz = w & 0x7FFFFFFFu;
         if (csz > ph.max_block) return make_err(LZ4F_ERROR_maxBlockSize_invalid);
         if (n - pos - 4 < csz + crc) return make_err(LZ4F_ERROR_frameHeader_incomplete);
@@ -164,10 +170,11 @@ size_t pipe_decompress_frame(const uint8_t* s, size_t n, const ParsedHeader& ph,
         pos += 4 + csz + crc;
         sl.count++; sl.src_len = pos - sl.src_at;
     }
-    pos += 4;                                                   // EndMark
+    if (endmark) pos += 4;
     const size_t nslab = slabs.size();
     const bool src_pinned = is_pinned_host(s), dst_pinned = flat && is_pinned_host(flat);
-    Xxh32State cck; cck.reset(0);
+    Xxh32State cck_here; cck_here.reset(0);
+    Xxh32State& cck = carry ? carry->cck : cck_here;
     const bool want_cck = ph.info.contentChecksumFlag != 0;
     Turns turns;
     size_t out_total = 0;
@@ -181,7 +188,8 @@ size_t pipe_decompress_frame(const uint8_t* s, size_t n, const ParsedHeader& ph,
         if (is_err(r)) return r;
         const size_t nslot = std::min(slots.eng.size(), nslab);
         std::vector<std::string> errs(nslot);
-        std::vector<uint8_t> hist_keep;                          // (linked + sink: the last 64 KiB handed over)
+        std::vector<uint8_t> hist_here;
+        std::vector<uint8_t>& hist_keep = carry ? carry->hist : hist_here;      // (linked + sink: the last 64 KiB handed over)
         bool ready = false; const uint8_t* ready_ptr = nullptr; size_t ready_len = 0;      // sink: the slab whose turn it is, waiting to be handed over
         auto work = [&](size_t slot) {
             lz4f_mi355x_engine* e = slots.eng[slot].e;
@@ -189,7 +197,7 @@ size_t pipe_decompress_frame(const uint8_t* s, size_t n, const ParsedHeader& ph,
                 const SlabD& sl = slabs[k];
                 std::vector<lz4f_mi355x_block> ent(entries.begin() + sl.first, entries.begin() + sl.first + sl.count);
                 const uint8_t* hist = nullptr; size_t hl = 0;
-                if (linked && k) {                               // (nslot == 1 here: the slab in front is complete)
+                if (linked && (k || (carry && !flat))) {         // (nslot == 1 here: the slab in front is complete; a batch's first slab: what the batch before left)
                     if (flat) { hl = std::min(turns.offset, (size_t)65536); hist = flat + turns.offset - hl; }
                     else { hl = hist_keep.size(); hist = hist_keep.data(); }
                 }
@@ -249,6 +257,7 @@ size_t pipe_decompress_frame(const uint8_t* s, size_t n, const ParsedHeader& ph,
         if (turns.err) { for (auto& m : errs) if (!m.empty()) { set_last_error("%s", m.c_str()); break; } return turns.err; }
         out_total = turns.offset;
     }
+    if (carry) { carry->out_total += out_total; *decoded = out_total; *consumed = pos; return 0; }
     if (ph.info.contentSize && ph.info.contentSize != out_total) return make_err(LZ4F_ERROR_frameSize_wrong);
     if (want_cck) {
         if (n - pos < 4) return make_err(LZ4F_ERROR_frameHeader_incomplete);

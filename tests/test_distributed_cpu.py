@@ -177,3 +177,12 @@ def test_bench_n_rank_path_on_a_shared_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["roundtrip_verified"] is True and d["scaling"] == "weak"
     assert d["config"]["rccl_ranks"] == 2 and d["config"]["bytes_per_gpu"] == 256 << 20 and d["value"] > 0
     assert abs(d["value"] - 2 * (256 << 20) * 2 / (d["ms_per_step"] * 2 * 1e-3) / 2**30) < 0.02 * d["value"]      # the aggregate of both ranks over the slowest rank's time
+    # the same launch with rank 0's one-frame leg behind the timed region: a single frame in page-locked host memory, its slabs dealt over
+    # the N devices by lz4f_mi355x_use_devices (two LOGICAL devices here), while the other rank waits on the rendezvous store
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--bytes", str(256 << 20), "--legs", "multi", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.returncode, r.stdout[-300:], r.stderr[-1200:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    m = d["multi_device_host"]
+    assert "error" not in m, m
+    assert d["n_gpus"] == 2 and m["devices"] == 2 and m["logical"] is True and m["roundtrip_verified"] is True and m["round_trip_GiBs"] > 0

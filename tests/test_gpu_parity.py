@@ -395,6 +395,56 @@ def test_batched_decoder_walks_whole_streams(L, golden, named_inputs):
         conduit.decompressBatched([forged])
 
 
+def test_batched_decoder_is_memory_bounded(L, named_inputs):
+    """decompressBatched must not gather the stream (the reference's decompress holds one max(hint, 16 KiB) buffer, Conduit.hsc:634-659):
+    the conduit cuts runs of whole blocks out of the chunks as they arrive and hands them to lz4f_mi355x_fdec_blocks batch by batch.
+    Output must start while most of the input has not been asked for yet; linked frames carry their 64 KiB of history from batch to
+    batch; content checksum and contentSize are checked over all batches; every framing gives the oracle's bytes."""
+    import ctypes
+    rng = np.random.default_rng(3)
+    data = np.concatenate([datagen.synth50(24 << 20, 9), rng.integers(0, 256, 3 << 20, dtype=np.uint8), np.frombuffer(datagen.synth_text(5 << 20, 2).tobytes(), dtype=np.uint8)]).tobytes()
+    framings = [dict(bsid=4, indep=0, cck=1), dict(bsid=4, indep=1, bck=1), dict(bsid=7, indep=1, cck=1, csize=len(data)), dict(bsid=5, indep=0, bck=1, cck=1), dict(bsid=6, indep=1)]
+    for kw in framings:
+        fr = oracle.conduit_compress(data, oracle.mkprefs(**kw))
+        stream = fr
+        for batch, step in ((1 << 20, 300007), (8 << 20, 1 << 20), (None, 65536)):
+            chunks = [stream[i:i + step] for i in range(0, len(stream), step)]
+            assert sha(b"".join(conduit.decompressBatched(chunks, batch))) == sha(data), (kw, batch, step)
+    # two frames and a skippable one, cut at awkward places
+    a = oracle.conduit_compress(data[:5 << 20], oracle.mkprefs(bsid=4, indep=0, cck=1)); b = oracle.conduit_compress(data[5 << 20:9 << 20], oracle.mkprefs(bsid=5, indep=1))
+    skip = bytes.fromhex("5e2a4d18") + (70001).to_bytes(4, "little") + bytes(70001)
+    stream = a + skip + b
+    for step in (1, 7, 4099):
+        cuts = [stream[:step], stream[step:len(a) - 2], stream[len(a) - 2:len(a) + 9], stream[len(a) + 9:len(a) + len(skip) + 3], stream[len(a) + len(skip) + 3:]]
+        assert b"".join(conduit.decompressBatched(cuts, 1 << 20)) == data[:9 << 20]
+    # bounded: with 1 MiB batches the first output arrives before a tenth of the input has been asked for
+    fr = oracle.conduit_compress(data, oracle.mkprefs(bsid=4, indep=0, cck=1))
+    pulled, first_out_at, got = [0], [None], []
+    it = iter(fr[i:i + 65536] for i in range(0, len(fr), 65536))
+    keep = [None]
+    def _await(_u, pdata):
+        try: c = next(it)
+        except StopIteration: pdata[0] = None; return 0
+        keep[0] = ctypes.create_string_buffer(c, len(c)); pdata[0] = ctypes.cast(keep[0], ctypes.c_void_p).value; pulled[0] += len(c); return len(c)
+    def _yield(_u, p, n):
+        if first_out_at[0] is None: first_out_at[0] = pulled[0]
+        got.append(ctypes.string_at(p, n))
+    err = ctypes.create_string_buffer(512)
+    rc = L.lz4f_mi355x_conduit_decompress_batched_bounded(1 << 20, _ffi.AWAIT_FN(_await), _ffi.YIELD_FN(_yield), None, err, 512)
+    assert rc == 0, err.value
+    assert b"".join(got) == data and first_out_at[0] is not None and first_out_at[0] < len(fr) // 10, (first_out_at[0], len(fr))
+    # errors keep their names when the damage is in a later batch
+    bad = bytearray(fr); bad[-2] ^= 1                                                # the content checksum
+    with pytest.raises(conduit.Lz4FrameError, match="ERROR_contentChecksum_invalid"):
+        conduit.decompressBatched([bytes(bad)], 1 << 20)
+    with pytest.raises(conduit.Lz4FrameError, match="stream ended before EndMark"):
+        conduit.decompressBatched([fr[:len(fr) * 2 // 3]], 1 << 20)
+    forged = oracle.conduit_compress(data[:3 << 20], oracle.mkprefs(bsid=4, indep=1, csize=(3 << 20)))
+    short = oracle.conduit_compress(data[:(3 << 20) - 1], oracle.mkprefs(bsid=4, indep=1))
+    with pytest.raises(conduit.Lz4FrameError, match="ERROR_frameSize_wrong"):
+        conduit.decompressBatched([forged[:15] + short[7:]], 1 << 20)
+
+
 # ------------------------------------------------------------------------------------------------
 # Sequence-shape fuzz: inputs built to hit every length class and overlap case of the copy paths (datagen.structured),
 # both directions, every block size, linked and independent, against the oracle (bit-exact with liblz4): 72 cases.

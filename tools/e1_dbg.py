@@ -1,24 +1,16 @@
 #!/usr/bin/env python3
-"""Dev tool (GPU box): one small compress through the device API (argv: MiB, bsid, linked, kind)."""
+"""Development (GPU box): one compress of synth50 / text with an -DE1_DEBUG build (LZ4F_MI355X_LIB=...): pass E1's phase stamps on stderr."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
-import oracle
+import torch
 from lz4_frame_conduit_amd import conduit, datagen
 from lz4_frame_conduit_amd.device import Engine, synth50_device
-mib = float(sys.argv[1]) if len(sys.argv) > 1 else 0.0625
-bsid = int(sys.argv[2]) if len(sys.argv) > 2 else 4
-linked = int(sys.argv[3]) if len(sys.argv) > 3 else 1
-kind = sys.argv[4] if len(sys.argv) > 4 else "random"
-n = int(mib * (1 << 20))
-if kind == "random": data = np.random.default_rng(7).integers(0, 256, n, dtype=np.uint8)
-elif kind == "text": data = datagen.synth_text(n, 99)
-else: data = datagen.synth50(n, 1234)
-src = torch.from_numpy(data).cuda(); eng = Engine(0)
-p = conduit.make_preferences(blockSizeID=bsid, blockMode=0 if linked else 1)
+what = sys.argv[1] if len(sys.argv) > 1 else "s50"
+n = 1 << 30
+src = synth50_device(n, 1234, "cuda") if what == "s50" else torch.from_numpy(datagen.synth_text(64 << 20, 99)).cuda().repeat(16)
+eng = Engine(0); eng.set_timing(True)
+p = conduit.make_preferences(blockSizeID=7, blockMode=1)
 frame = torch.empty(eng.frame_bound(n, p), dtype=torch.uint8, device="cuda")
-print("launch", flush=True)
-eng.compress_async(src, frame, p); r = eng.result()
-print("size", r.size, "status", r.status, flush=True)
-out, used = oracle.decompress_frame(frame[:r.size].cpu().numpy().tobytes(), cap=n + 64)
-print("oracle roundtrip", out == data.tobytes(), "ratio %.4f" % (n / r.size))
+for it in range(2):
+    eng.compress_async(src, frame, p); r = eng.result(); t = eng.get_timing()
+print(what, "e1 ms", round(t["find_matches"], 3), "ratio", round(n / r.size, 4))
