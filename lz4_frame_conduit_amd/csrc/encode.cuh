@@ -130,6 +130,7 @@ struct alignas(16) E1Shared {
     uint32_t cur[16];                        // per wave: the slice it has (a lower bound while it is between slices; ~0 when it is through with the tile)
     uint32_t pieces[2];                      // 4 KiB pieces of the NEXT tile already requested (by tile parity)
     uint32_t mode, hits;                     // 0: density of the data not known yet, 1: sparse (long sequences), 2: dense; sequences found while it is not known
+    uint32_t tail_d[2];                      // by tile parity: the distance of a match that was cut at the tile's end (0: none) - see E1_OPENER
     uint32_t idle[64];                       // where lanes 1..63 point their share of a wave-wide atomic
     alignas(16) uint8_t ring[E1_RING + 16];  // + the first 16 bytes again, so that a read across the end needs no wrap
 };
@@ -166,6 +167,11 @@ static_assert(64 * E1_WAVES >= E1_NSLICE, "a thread per slice when the lists are
 // 1.9615 without against 1.9613 with, text 1.8584 both; 3.56 against 3.66 ms)
 #ifndef E1_IP2
 #define E1_IP2 0
+#endif
+// Round 4.  The tile's first slice goes to the first wave alone (see the loop); the other fifteen wait for it only where the tile before
+// ended inside a match (E1_OPENER 2) - the case the wait is there for - instead of always (1); 0: never.
+#ifndef E1_OPENER
+#define E1_OPENER 2
 #endif
 constexpr uint32_t E1_GRAB_SPARSE = E1_GRAB, E1_GRAB_DENSE = E1_GRAB_D, E1_PROBE_SLICES = 16, E1_DENSE_HITS = 24;
 
@@ -436,9 +442,10 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
         }
     };
 
-    if (tid == 0) { sh.mode = 0; sh.cov = E1_TILE; sh.hits = 0; sh.first = 0; sh.next = 1; sh.pieces[0] = 0; sh.pieces[1] = 0; }
+    if (tid == 0) { sh.mode = 0; sh.cov = E1_TILE; sh.hits = 0; sh.first = 0; sh.next = 1; sh.pieces[0] = 0; sh.pieces[1] = 0; sh.tail_d[0] = 0; sh.tail_d[1] = 0; }
     if (tid < 16) sh.cur[tid] = 0;
     uint32_t mode_tile = 0;                                              // (deterministic parse) sh.mode as it stood when this tile began
+    uint32_t hold = 1;                                                   // this tile's first slice is waited for: the tile before was left inside a match that goes on
     bool pend = false;                                                   // a tile whose lists are not merged yet
     uint32_t p_c = 0, p_par = 0, p_ts = 0, p_te = 0, p_bend = 0, p_ns = 0;
     __syncthreads();                                                     // the first tile is in the ring, the table is seeded, counters are set
@@ -506,7 +513,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
             const uint32_t grab = opener ? 1u : mode == 1 ? E1_GRAB_SPARSE : mode == 2 ? E1_GRAB_DENSE : 1u;
             uint32_t si = 0;
             if (!opener) {
-                if (fresh) for (uint32_t spin = 0; spin < 4096 && uni(__hip_atomic_load(&sh.first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0; spin++) __builtin_amdgcn_s_sleep(2);
+                if (fresh && E1_OPENER && (E1_OPENER == 1 || hold)) for (uint32_t spin = 0; spin < 4096 && uni(__hip_atomic_load(&sh.first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0; spin++) __builtin_amdgcn_s_sleep(2);
                 si = uni(atomicAdd(lane == 0 ? &sh.next : &sh.idle[lane], grab));
             }
             fresh = false;
@@ -774,6 +781,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                     anchor = ip = mp + mlen;
                     step = 1; two = 1;
                     atomicMax(lane == 0 ? &sh.cov : &sh.idle[lane], ip);
+                    if (E1_OPENER == 2) *((lane == 0 && ip == end_lim) ? &sh.tail_d[par] : &sh.idle[lane]) = d;      // (cut at the tile's end: the next tile's first slice may find the rest)
                     // like the CPU encoder, also index ip - 2
                     E1DBG(a_hit += clock64() - z2;)
                     if (E1_IP2 && ip >= low + 2 && ip + 2 <= te) { const uint32_t q2 = ip - 2, hv2 = e1_mix(e1_ld32(sh.ring, q2)); *(lane == 0 ? &sh.table[e1_slot(hv2)] : (uint16_t*)&sh.idle[lane]) = (uint16_t)q2; *(lane == 0 ? &sh.tags[e1_slot(hv2)] : (uint8_t*)&sh.idle[lane]) = (uint8_t)e1_tag(hv2); }
@@ -794,7 +802,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
         pend = true; p_c = c; p_par = par; p_ts = ts; p_te = te; p_bend = bend; p_ns = nslice;
 
         // ---- what is left of the next tile into the ring; counters for it ----
-        if (tid == 0) { sh.cov = nts; sh.hits = 0; sh.first = 0; sh.next = 1; sh.pieces[par ^ 1u] = 0; }      // (slice 0 is the first wave's)
+        if (tid == 0) { sh.tail_d[par ^ 1u] = 0; sh.cov = nts; sh.hits = 0; sh.first = 0; sh.next = 1; sh.pieces[par ^ 1u] = 0; }      // (slice 0 is the first wave's)
         if (tid < 16) sh.cur[tid] = 0;
         if (nlen) {
             if (nlen_full) {
@@ -808,6 +816,10 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // my part of the next tile has landed
         E1DBG(const unsigned long long q5 = clock64();)
         __syncthreads();
+        {   // does the match that was cut at this tile's end go on in the next one?  (its bytes are in the ring now)
+            const uint32_t td = uni(__hip_atomic_load(&sh.tail_d[par], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            hold = (g.e1_solo & 1u) || (td != 0 && nlen >= 4 && uni(e1_ld32(sh.ring, nts)) == uni(e1_ld32(sh.ring, nts - td))) ? 1u : 0u;
+        }
         E1DBG(if (blockIdx.x == 0 && lane == 0) { unsigned long long* d = (unsigned long long*)&scratch[E1_DBG_AT + 16 + wave * 8]; d[0] += q1 - q0; d[1] += q2 - q1; d[2] += q3 - q2; d[3] += q4 - q3; d[4] += q5 - q4; d[5] += clock64() - q5; d[6] += 1; unsigned long long* f = (unsigned long long*)&scratch[E1_DBG_AT + 160 + wave * 6]; f[0] += a_deq; f[1] += a_probe; f[2] += a_hit; f[3] += n_deq; f[4] += n_step; f[5] += n_hit; })
     }
     if (pend && wave == E1_WAVES - 1) merge(p_c, p_par, p_ts, p_te, p_bend, p_ns);
