@@ -28,6 +28,10 @@ namespace lz4f {
 template <int W> struct FzCfg;
 template <> struct FzCfg<8> { static constexpr int WAVES = 8; static constexpr uint32_t STAGE = 8192, RING = 8, LDS_BUDGET = 40960; };
 template <> struct FzCfg<4> { static constexpr int WAVES = 4; static constexpr uint32_t STAGE = 2048, RING = 4, LDS_BUDGET = 20480; };
+// the shapes of the self-feeding copy kernel (decode_indexed.cuh: k_copy_selffed): no payload stages (the area holds a ring of output positions
+// instead), and a descriptor ring twice as deep - its first wave parses in rounds, and the copiers live off the ring meanwhile
+struct FzCfgS8 { static constexpr int WAVES = 8; static constexpr uint32_t STAGE = 4096 - 576, RING = 16, LDS_BUDGET = 40960; };
+struct FzCfgS4 { static constexpr int WAVES = 4; static constexpr uint32_t STAGE = 2048, RING = 8, LDS_BUDGET = 20480; };
 constexpr uint32_t FZ_OVER = 576;                // >= the parser's 520-byte register window + 8
 #ifndef FZ_FED_ROUNDS
 #define FZ_FED_ROUNDS 1                          // gather rounds per register set in the fed copiers (two sets in flight)
@@ -69,6 +73,7 @@ struct alignas(16) FzShared {
     uint32_t wait_hi;
 };
 static_assert(sizeof(FzShared<FzCfg<8>>) <= FzCfg<8>::LDS_BUDGET && sizeof(FzShared<FzCfg<4>>) <= FzCfg<4>::LDS_BUDGET, "workgroups per CU");
+static_assert(sizeof(FzShared<FzCfgS8>) <= FzCfgS8::LDS_BUDGET && sizeof(FzShared<FzCfgS4>) <= FzCfgS4::LDS_BUDGET, "workgroups per CU");
 
 __device__ __forceinline__ uint32_t lds_peek(const uint32_t* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
 __device__ __forceinline__ void lds_poke(uint32_t* p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELAXED); }
@@ -352,7 +357,8 @@ __device__ __forceinline__ void fz_copier(FzShared<C>& sh, const uint8_t* __rest
 {
     const uint32_t lane = lane_id();
     unsigned long long t_wait_p = 0, t_lit = 0, t_wait_m = 0, t_match = 0, n_slots = 0, t_dep = 0, t_drain = 0;
-    auto dump = [&]() { if (prof && blockIdx.x == 0 && lane == 0) { unsigned long long* o = prof + 8 * (cw + 1); o[0] = t_wait_p; o[1] = t_lit; o[2] = t_wait_m; o[3] = t_match; o[4] = n_slots; o[5] = t_dep; o[6] = t_drain; } };
+    auto dump = [&]() { if (prof && FED && lane == 0) { atomicAdd(prof + 76, t_wait_p); atomicAdd(prof + 77, t_lit); atomicAdd(prof + 78, t_wait_m); atomicAdd(prof + 79, t_match); }
+                        if (prof && blockIdx.x == 0 && lane == 0) { unsigned long long* o = prof + 8 * (cw + 1); o[0] = t_wait_p; o[1] = t_lit; o[2] = t_wait_m; o[3] = t_match; o[4] = n_slots; o[5] = t_dep; o[6] = t_drain; } };
     for (uint32_t slot = cw;; slot += C::WAVES - 1) {
         // wait for the slot (or for the end of the block)
         const unsigned long long c0 = clock64();

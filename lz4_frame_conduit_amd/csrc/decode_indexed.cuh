@@ -78,8 +78,9 @@ __global__ void k_check_index(const void* __restrict__ ix, uint64_t ix_size, uin
 // is where the next run starts).  `is_tail`: the run holds the block's last sequence.  `out_front`: output bytes in front of the
 // block that a match of a linked frame may reach.
 __device__ __forceinline__ bool parse_run(const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable, uint32_t& pos, uint32_t op, uint32_t my_nseq,
-                                          bool is_tail, SeqDesc* __restrict__ out, uint32_t linked, uint64_t out_front)
-{
+                                          bool is_tail, SeqDesc* __restrict__ out, uint32_t linked, uint64_t out_front,
+                                          uint32_t* opr = nullptr, uint32_t seq0 = 0, uint32_t omask = 0)
+{   // opr: (the feeder that parses for itself, fz_feeder_parse) every sequence's output position also goes into a ring in LDS
     bool bad = false;
     // the last four output ranges whose bytes are known to sit in the payload (literal runs, and matches that copied from such a
     // range): a match that lies inside one is DIRECT -- a plain copy out of the payload that needs no earlier output
@@ -87,7 +88,11 @@ __device__ __forceinline__ bool parse_run(const uint8_t* __restrict__ in, uint32
     auto remember = [&](uint32_t o, uint32_t n, uint32_t pp) { r3o = r2o; r3n = r2n; r3p = r2p; r2o = r1o; r2n = r1n; r2p = r1p; r1o = r0o; r1n = r0n; r1p = r0p; r0o = o; r0n = n; r0p = pp; };
     // One dependent load per sequence: the 16 bytes at the match offset also hold the match-length bytes, the NEXT token and
     // its literal-length bytes (a lane walks its sequences at memory latency, so the loads on that chain are what counts).
+    // (The descriptor of sequence i is stored BEHIND the load of sequence i + 1: loads and stores share one counter and come back in issue
+    // order, so a store in front of the load would put a write's round trip on the chain as well - in the feeder that parses for itself
+    // that was 9.6 k cycles per sequence instead of one memory latency.)
     uint64_t w, w_hi;
+    SeqDesc pend{0u, 0u, 0u, 0u};
     pt_load16(in, pos, readable, w, w_hi);
     for (uint32_t i = 0; i < my_nseq && !bad; i++) {
         if (pos >= csize) { bad = true; break; }
@@ -109,6 +114,9 @@ __device__ __forceinline__ bool parse_run(const uint8_t* __restrict__ in, uint32
             const uint32_t q = p + lit;
             uint64_t w2, w2_hi;
             pt_load16(in, q, readable, w2, w2_hi);
+            __builtin_amdgcn_sched_barrier(0);
+            if (i) out[i - 1] = pend;
+            __builtin_amdgcn_sched_barrier(0);
             off = (uint32_t)w2 & 0xFFFF;
             if (off == 0) { bad = true; break; }
             mlen = token & 15; uint32_t pn = q + 2;
@@ -144,7 +152,10 @@ __device__ __forceinline__ bool parse_run(const uint8_t* __restrict__ in, uint32
             }
             if (msrc < IX_SRC_BIAS) { f24 = msrc + IX_SRC_BIAS; mw |= 0x80000000u; remember(dm, mlen, msrc); }
         }
-        out[i] = SeqDesc{p | ((f24 & 0xFFu) << 24), lit | (((f24 >> 8) & 0xFFu) << 24), op, mw | (((f24 >> 16) & 0x7Fu) << 24)};
+        if (i && !mlen) out[i - 1] = pend;                                     // (the block's last sequence: no load was issued)
+        pend = SeqDesc{p | ((f24 & 0xFFu) << 24), lit | (((f24 >> 8) & 0xFFu) << 24), op, mw | (((f24 >> 16) & 0x7Fu) << 24)};
+        if (i + 1 == my_nseq) out[i] = pend;
+        if (opr) opr[(seq0 + i) & omask] = op;
         op += lit + mlen;
     }
     return bad;
@@ -1064,6 +1075,284 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_indexed(cons
         // (this release is what a linked frame of small blocks costs, hence the groups)
         __threadfence();
         __hip_atomic_store(done + g, failed ? 2u : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: ONE kernel for independent blocks that come with an index (the compressor's out of the trailer, or - decode_spx.cuh - the
+// stretch points a foreign frame was cut into).  k_parse_indexed and k_resolve_direct were kernels of their own in front of the
+// copy (0.23 + 0.12 ms of the bench decode's 1.78, and three launch boundaries); here the workgroup's FIRST WAVE does both for its
+// block while the copier waves already move bytes:
+//   * parse: the lanes take the block's next runs (index entries of <= 16 sequences, or stretches), each walks its run with
+//     parse_run() - the same code, the same rules - and writes the descriptors to the workspace in HBM; every sequence's output
+//     position also goes into a ring in LDS (the stage area the parser wave of the generic decoder uses: 4096 words, 1024 in the
+//     4-wave shape).  A round takes as many runs as hold at most half a ring of sequences.
+//   * resolve, per ring slot of 64 descriptors: a lane whose match is not direct yet looks for the sequence that produced its first
+//     source byte - a binary search over the ring (LDS), then ONE read of that descriptor (written by this wave a moment ago: L2) -
+//     and follows plain matches a few hops, like k_resolve_direct.  What it finds is written back into the descriptor, so later
+//     hops end at the first direct match.  A source older than the ring remembers (4096 sequences: more than 64 KiB of anything
+//     that is not dense) stays on the chain.
+//   * then the slot is checked (tiling, room, offsets) and published exactly as fz_feeder does.
+// A block's feeder needs ~0.3 ms of its ~1.4; the copiers are never the ones waiting after the first round.  Anything odd sets
+// flags bit 1 and the generic decoder launched behind decodes the frame again, as with k_copy_indexed.
+template <class C> struct FzOpr { static constexpr uint32_t N = (2u * (C::STAGE + FZ_OVER) >= 16384u) ? 4096u : (2u * (C::STAGE + FZ_OVER) >= 8192u) ? 2048u : 1024u; };
+static_assert(FzOpr<FzCfgS8>::N * 4 <= 2 * (FzCfgS8::STAGE + FZ_OVER) && FzOpr<FzCfgS4>::N * 4 <= 2 * (FzCfgS4::STAGE + FZ_OVER), "the ring of output positions lives in the stage area");
+
+struct FzRun { uint32_t in_off, out_pos, seq_off, nseq, stop; bool tail, bad; };
+// the runs of one block out of an index: its entries
+struct FzRunsIx {
+    const IxEntry* ent; uint32_t n, b, nseq_blk, csize;
+    __device__ __forceinline__ uint32_t count() const { return n; }
+    __device__ __forceinline__ FzRun get(uint32_t u) const
+    {
+        const IxEntry me = ent[u];
+        FzRun r{me.in_off, me.out_pos, me.seq_off, me.nseq_blk & 0xFFu, 0u, u + 1 == n, false};
+        r.bad = (me.nseq_blk >> 8) != b || r.nseq == 0 || me.in_off >= csize || (uint64_t)me.seq_off + r.nseq > nseq_blk;
+        if (u == 0) r.bad |= (me.in_off | me.out_pos | me.seq_off) != 0;       // the entries must cover the payload from its first byte
+        if (r.tail) { r.stop = csize; r.bad |= me.seq_off + r.nseq != nseq_blk; }
+        else { const IxEntry nx = ent[u + 1]; r.stop = nx.in_off; r.bad |= nx.seq_off != me.seq_off + r.nseq; }
+        return r;
+    }
+};
+
+template <class C, class RUNS>
+__device__ __forceinline__ void fz_feeder_parse(FzShared<C>& sh, const RUNS& runs, const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable,
+                                                SeqDesc* desc, uint32_t nseq, uint32_t cap, unsigned long long* prof)
+{
+    constexpr uint32_t OPR = FzOpr<C>::N, OMASK = OPR - 1, ROUND_MAX = OPR / 2;
+    unsigned long long t_parse = 0, t_res = 0, t_ring = 0, n_round = 0, t_load = 0;
+    const unsigned long long t_begin = clock64();
+    uint32_t* opr = (uint32_t*)&sh.stage[0][0];
+    const uint32_t lane = lane_id();
+    uint32_t per = (nseq + (C::WAVES - 1) - 1) / (C::WAVES - 1);
+    per = per > 64 ? 64u : (per < 8 ? 8u : per);
+    const uint32_t nslots = (nseq + per - 1) / per, nruns = runs.count();
+    uint32_t expect = 0, status = nseq ? 0u : 1u, published = 0;
+    uint32_t W = 0, u0 = 0;                                                  // sequences parsed so far (descriptors in HBM, positions in the ring); next run
+    uint4 nxt = {0u, 0u, 0u, 0u}; bool nxt_ok = false;
+    for (uint32_t slot = 0; slot < nslots && !status; slot++) {
+        const uint32_t first = slot * per;
+        const uint32_t count = (nseq - first < per) ? nseq - first : per;
+        // ---- parse until this slot's sequences are there ----
+        const unsigned long long z0 = clock64();
+        while (W < first + count) {
+            n_round++;
+            if (u0 >= nruns) { status = 1; break; }
+            const bool have = u0 + lane < nruns;
+            FzRun r{0u, 0u, 0u, 0u, 0u, false, false};
+            if (have) r = runs.get(u0 + lane);
+            uint32_t tot;
+            const uint32_t before = wave_excl_scan(have ? r.nseq : 0u, tot);
+            const uint64_t refused = __ballot(have && lane != 0 && before + r.nseq > ROUND_MAX), hv = __ballot(have);
+            const uint32_t R = refused ? (uint32_t)__builtin_ctzll(refused) : (uint32_t)__builtin_popcountll(hv);      // (a prefix of the lanes)
+            const bool mine = lane < R;
+            bool bad = mine && (r.bad || r.nseq > ROUND_MAX || (lane == 0 && r.seq_off != W));
+            uint32_t pos = r.in_off;
+            if (mine && !bad) {
+                bad = parse_run(in, csize, readable, pos, r.out_pos, r.nseq, r.tail, desc + r.seq_off, 0u, 0ull, opr, r.seq_off, OMASK);
+                bad |= pos != r.stop;                                        // must end exactly where the next run starts
+            }
+            if (__ballot(bad)) { status = 1; break; }
+            W = (uint32_t)__builtin_amdgcn_readlane((int)(r.seq_off + r.nseq), (int)(R - 1));
+            u0 += R;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        if (status) break;
+        const unsigned long long z1 = clock64(); t_parse += z1 - z0;
+        uint4 d = nxt;
+        if (!nxt_ok && lane < count) d = ((const uint4*)desc)[first + lane];
+        nxt_ok = false;
+        if (slot + 1 < nslots) {                                             // the next slot's descriptors travel while this one is resolved, if they are parsed already
+            const uint32_t nf = first + per, nc = (nseq - nf < per) ? nseq - nf : per;
+            if (W >= nf + nc) { nxt = uint4{0u, 0u, 0u, 0u}; if (lane < nc) nxt = ((const uint4*)desc)[nf + lane]; nxt_ok = true; }
+        }
+        const unsigned long long z2 = clock64(); t_load += z2 - z1;
+        // ---- resolve: where in the payload do my match's bytes come from? ----
+        {
+            const uint32_t ml = d.w & 0xFFFFFFu;
+            uint32_t found = IX_NOT_DIRECT;
+            if (lane < count && ml != 0 && !(d.w >> 31)) {
+                const uint32_t off = (d.x >> 24) | ((d.y >> 24) << 8), dm = d.z + (d.y & 0xFFFFFFu);
+                if (ml <= off && off <= dm) {                                // (overlapping matches replicate their own output: never direct)
+                    uint32_t key = dm - off, hi = first + lane;
+                    const uint32_t ring_lo = W > OPR ? W - OPR : 0u;
+                    for (uint32_t hop = 0; hop < IXR_HOPS; hop++) {
+                        if (hi < ring_lo) break;
+                        const uint32_t olo = opr[ring_lo & OMASK], ohi = opr[hi & OMASK];
+                        if (olo > key) break;                                // older than the ring remembers
+                        // the last sequence that starts at or before key.  A guess from the average sequence length first, then outwards
+                        // from it in doubling steps, then bisection: 3-4 LDS reads where sequences are of a size (12 for plain bisection)
+                        uint32_t lo = ring_lo;                               // (opr[lo] <= key, opr[hi + 1] > key throughout)
+                        if (ohi <= key) lo = hi;
+                        else {
+                            uint32_t g = lo + (uint32_t)((float)(key - olo) * (float)(hi - lo) / (float)(ohi - olo));
+                            g = g >= hi ? hi - 1 : g;
+                            uint32_t step = 1;
+                            if (opr[g & OMASK] <= key) {
+                                lo = g; hi = hi - 1;
+                                while (lo + step <= hi) {
+                                    if (opr[(lo + step) & OMASK] <= key) { lo += step; step <<= 1; }
+                                    else { hi = lo + step - 1; break; }
+                                }
+                            } else {
+                                hi = g - 1;                                  // (g > lo: opr[lo] <= key < opr[g])
+                                while (hi + 1 >= lo + step) {
+                                    const uint32_t t = hi + 1 - step;
+                                    if (opr[t & OMASK] > key) { hi = t - 1; step <<= 1; }
+                                    else { lo = t; break; }
+                                }
+                            }
+                        }
+                        while (lo < hi) {
+                            const uint32_t mid = (lo + hi + 1) >> 1;
+                            if (opr[mid & OMASK] <= key) lo = mid; else hi = mid - 1;
+                        }
+                        const SeqDesc dj = desc[lo];
+                        const uint32_t opj = dj.z, litj = dj.y & 0xFFFFFFu, mlj = dj.w & 0xFFFFFFu, dmj = opj + litj;
+                        const uint32_t fj = (dj.x >> 24) | ((dj.y >> 24) << 8);
+                        if (key < opj) break;
+                        if ((uint64_t)key + ml <= dmj) {                     // in its literal run
+                            const uint32_t v = (dj.x & 0xFFFFFFu) + (key - opj) + IX_SRC_BIAS;
+                            if (v < (1u << 23)) found = v;
+                            break;
+                        }
+                        if (key < dmj || (uint64_t)key + ml > (uint64_t)dmj + mlj) break;      // straddles
+                        if (dj.w >> 31) {                                    // in a direct match
+                            const uint32_t v = (fj | (((dj.w >> 24) & 0x7Fu) << 16)) + (key - dmj);      // (already biased)
+                            if (v < (1u << 23)) found = v;
+                            break;
+                        }
+                        if (fj == 0 || mlj > fj || fj > key) break;          // in a run-length match
+                        key -= fj; hi = lo;                                  // in a plain match: follow it
+                    }
+                }
+            }
+            if (found != IX_NOT_DIRECT) {
+                d = uint4{(d.x & 0xFFFFFFu) | ((found & 0xFFu) << 24), (d.y & 0xFFFFFFu) | (((found >> 8) & 0xFFu) << 24), d.z,
+                          (d.w & 0xFFFFFFu) | 0x80000000u | ((found >> 16) << 24)};
+                ((uint4*)desc)[first + lane] = d;                            // (later hops end here)
+            }
+        }
+        // ---- check and publish (as fz_feeder) ----
+        const unsigned long long z3 = clock64(); t_res += z3 - z2;
+        const uint32_t p = d.x & 0xFFFFFFu, lit = d.y & 0xFFFFFFu, op = d.z, ml = d.w & 0xFFFFFFu;
+        const bool direct = (d.w >> 31) != 0;
+        const uint32_t f24 = (d.x >> 24) | ((d.y >> 24) << 8) | (((d.w >> 24) & 0x7Fu) << 16);
+        const uint64_t dm = (uint64_t)op + lit, end = dm + ml;
+        const uint32_t prev_end = __shfl_up((uint32_t)end, 1);
+        const bool last = first + lane + 1 == nseq;
+        bool bad = op != (lane == 0 ? expect : prev_end) || (uint64_t)p + lit > csize || end > cap;
+        if (last) bad |= ml != 0 || direct;
+        else {
+            bad |= ml < 4 || end + 5 > cap;
+            const int64_t rel = (int64_t)f24 - (int64_t)FZ_SRC_BIAS;
+            bad |= direct ? (rel < 0 || rel + (int64_t)ml > (int64_t)csize) : (f24 == 0 || f24 > 65535u || f24 > dm);
+        }
+        if (__ballot(lane < count && bad)) { status = 1; break; }
+        expect = __shfl((uint32_t)end, (int)count - 1);
+        const unsigned long long z4 = clock64();
+        while (slot >= lds_peek(&sh.match_done) + C::RING && (int32_t)lds_peek((const uint32_t*)&sh.status) >= 0) __builtin_amdgcn_s_sleep(8);
+        t_ring += clock64() - z4;
+        if ((int32_t)lds_peek((const uint32_t*)&sh.status) < 0) { status = 1; break; }
+        sh.ring[slot % C::RING][lane] = d;
+        sh.slot_cnt[slot % C::RING] = count;
+        if (slot + 1 == nslots) break;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        lds_poke(&sh.produced, slot + 1);
+        published = slot + 1;
+    }
+    if (prof && lane == 0) { const unsigned long long tt = clock64() - t_begin; atomicMax(prof + 66, tt); atomicAdd(prof + 67, tt); atomicAdd(prof + 68, t_ring); atomicAdd(prof + 73, t_parse); atomicAdd(prof + 74, t_res); }
+    if (prof && blockIdx.x == 0 && lane == 0) { prof[0] = clock64() - t_begin; prof[1] = t_ring; prof[2] = nseq; prof[3] = t_parse; prof[4] = t_load; prof[5] = t_res; prof[6] = n_round; }
+    if (!status && (W != nseq || u0 != nruns)) status = 1;                  // every run used, every sequence parsed
+    sh.total_slots = status ? published : nslots;
+    sh.last_count = status ? 64u : nseq - (nslots - 1) * per;
+    sh.out_size = expect;
+    sh.status = status ? -1 : 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lds_poke(&sh.finished, 1u);
+    if (!status) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); lds_poke(&sh.produced, nslots); }
+}
+
+// the workgroup of fz_decode_block<C, true>, its first wave feeding itself
+template <class C, class RUNS>
+__device__ __forceinline__ int32_t fz_decode_block_self(FzShared<C>& sh, const RUNS& runs, const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable,
+                                                        uint8_t* out, uint32_t cap, const uint8_t* safe, unsigned long long* prof, SeqDesc* desc, uint32_t nseq)
+{
+    const uint32_t wave = uni(threadIdx.x >> 6);
+    __syncthreads();
+    if (threadIdx.x == 0) { sh.produced = 0; sh.total_slots = 0; sh.last_count = 64; sh.finished = 0; sh.match_done = 0; sh.status = 0; sh.out_size = 0; sh.pend_n = 0; sh.prev_ready = 0; sh.own_front = 0; }
+    if (threadIdx.x < C::RING) sh.slot_done[threadIdx.x] = 0;
+    __syncthreads();
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        fz_feeder_parse<C, RUNS>(sh, runs, in, csize, readable, desc, nseq, cap, prof);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    else fz_copier<C, true>(sh, in, out, wave - 1, safe, prof, nullptr);
+    __syncthreads();
+    const int32_t st = (int32_t)uni((uint32_t)sh.status);
+    const uint32_t osz = uni(sh.out_size);
+    return st < 0 ? -1 : (int32_t)osz;
+}
+
+// RSRC: what gives a block its runs (FzSrcIx below; FzSrcSpx in decode_spx.cuh)
+struct FzSrcIx {
+    const void* ix; uint32_t n_blocks;
+    __device__ __forceinline__ bool make(uint32_t b, const IxBlock& blk, uint32_t csize, uint32_t n_entries /* k_check_index: inside the buffer */, FzRunsIx& r) const
+    {
+        if ((uint64_t)blk.entry_base + blk.nentries > n_entries || blk.nentries == 0) return false;
+        r = FzRunsIx{ix_entries(ix, n_blocks) + blk.entry_base, blk.nentries, b, blk.nseq, csize};
+        return true;
+    }
+    typedef FzRunsIx Runs;
+};
+
+template <class C, class RSRC>
+__global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_selffed(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint8_t* dst, BlockOut* __restrict__ table,
+                                                                   const ResultRec* __restrict__ res, uint32_t n_max, const void* __restrict__ ix,
+                                                                   SeqDesc* desc, uint32_t* __restrict__ flags, unsigned long long* prof, RSRC rsrc)
+{
+    __shared__ FzShared<C> sh;
+    if (res->status != ST_OK || *flags || flags[IXT_FLAG]) return;           // index unusable (k_check_index): the generic kernel launched behind does the work
+    const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    const uint32_t b = blockIdx.x, tid = threadIdx.x;
+    const unsigned long long wg_t0 = prof ? __builtin_amdgcn_s_memrealtime() : 0ull, wg_c0 = prof ? clock64() : 0ull;
+    if (b >= n) return;
+    const uint64_t desc_cap = flags[9];
+    const BlockOut e = table[b];
+    const uint32_t csz = e.word & 0x7FFFFFFFu;
+    const IxBlock* blocks = ix_blocks(ix);
+    const IxBlock blk = blocks[b];
+    // the index's block table must hand out the descriptors and the entries without gaps or overlaps (every descriptor is then
+    // written by exactly one workgroup), and a compressed block without sequences cannot be decoded from the index
+    const bool stored = (e.word >> 31) != 0;
+    bool wrong = stored ? (blk.nentries != 0 || blk.nseq != 0) : blk.nseq == 0;
+    if (b == 0) wrong |= blk.seq_base != 0 || blk.entry_base != 0;
+    const uint64_t seq_end = (uint64_t)blk.seq_base + blk.nseq, ent_end = (uint64_t)blk.entry_base + blk.nentries;
+    if (b + 1 < n) { const IxBlock nb = blocks[b + 1]; wrong |= nb.seq_base != seq_end || nb.entry_base != ent_end; }
+    else wrong |= seq_end != desc_cap;
+    wrong |= e.src_off + csz > frame_cap;
+    int32_t got = -1;
+    if (!wrong) {
+        if (stored) {                                                        // stored block: all waves copy a slice
+            got = -2;
+            if (csz <= e.dst_size) {
+                const uint32_t per = (((csz + C::WAVES - 1) / C::WAVES) + 15) & ~15u;
+                const uint32_t a = (tid >> 6) * per;
+                if (a < csz) wave_copy_disjoint(dst + e.dst_off + a, frame + e.src_off + a, (csz - a < per) ? csz - a : per);
+                got = (int32_t)csz;
+            }
+        } else {
+            typename RSRC::Runs runs;
+            if (rsrc.make(b, blk, csz, flags[8], runs))
+                got = fz_decode_block_self<C>(sh, runs, frame + e.src_off, csz, frame_cap - e.src_off, dst + e.dst_off, e.dst_size, frame, prof, desc + blk.seq_base, blk.nseq);
+        }
+    }
+    if (tid == 0) { if (got < 0) atomicOr(flags, 2u); else table[b].dst_size = (uint32_t)got; }
+    if (prof && tid == 0) {                                                  // developer aid: how the workgroups of the grid spread in time
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime(), cc = clock64() - wg_c0;
+        atomicMax(prof + 64, cc); atomicAdd(prof + 65, cc); atomicMin(prof + 70, wg_t0); atomicMax(prof + 71, wg_t0); atomicMax(prof + 72, t1); atomicMin(prof + 75, t1);
     }
 }
 

@@ -316,4 +316,30 @@ __global__ __launch_bounds__(128) void k_spx_parse(const uint8_t* __restrict__ f
     }
 }
 
+
+// ---- round 4: the stretches as the runs of the self-feeding copy kernel (decode_indexed.cuh: k_copy_selffed) - k_spx_parse and
+// ---- k_resolve_direct are then not launched: the workgroup's first wave parses a round of stretches and resolves slot by slot
+struct FzRunsSpx {
+    const SpxPoint* T; uint32_t n, nseq_blk, csize;
+    __device__ __forceinline__ uint32_t count() const { return n; }
+    __device__ __forceinline__ FzRun get(uint32_t u) const
+    {
+        const SpxPoint from = T[u], to = T[u + 1];
+        FzRun r{from.pos, from.out, from.seq, to.seq - from.seq, to.pos, u + 1 == n, false};
+        r.bad = to.seq <= from.seq || to.seq > nseq_blk || (r.tail && (to.seq != nseq_blk || to.pos != csize)) || (u == 0 && (from.pos | from.seq | from.out) != 0) || from.pos >= csize;
+        return r;
+    }
+};
+struct FzSrcSpx {
+    const SpxPoint* T; const uint32_t* nr;
+    typedef FzRunsSpx Runs;
+    __device__ __forceinline__ bool make(uint32_t b, const IxBlock& blk, uint32_t csize, uint32_t, FzRunsSpx& r) const
+    {
+        const uint32_t stretches = nr[b];
+        if (stretches == 0 || stretches > SPX_MAXSEG) return false;
+        r = FzRunsSpx{T + (size_t)b * (SPX_MAXSEG + 1), stretches, blk.nseq, csize};
+        return true;
+    }
+};
+
 }  // namespace lz4f

@@ -85,7 +85,7 @@ void lz4f_mi355x_engine::Switches::read()
     no_index = on("LZ4F_MI355X_NO_INDEX"); no_selfindex = on("LZ4F_MI355X_NO_SELFINDEX"); no_resolve = on("LZ4F_MI355X_NO_RESOLVE");
     no_trace = on("LZ4F_MI355X_NO_TRACE"); no_doubling = on("LZ4F_MI355X_NO_DOUBLING"); trace_always = on("LZ4F_MI355X_TRACE_ALWAYS");
     no_groups = on("LZ4F_MI355X_NO_GROUPS"); no_window = on("LZ4F_MI355X_NO_WINDOW"); serial_walk = on("LZ4F_MI355X_SERIAL_WALK");
-    no_trailer = on("LZ4F_MI355X_NO_TRAILER"); no_density_probe = on("LZ4F_MI355X_NO_DENSITY_PROBE"); no_spx = on("LZ4F_MI355X_NO_SPX"); no_overlap = on("LZ4F_MI355X_NO_OVERLAP"); no_content_check = on("LZ4F_MI355X_NO_CONTENT_CHECK"); prof = on("LZ4F_MI355X_PROF"); e1_sync = on("LZ4F_MI355X_E1_SYNC");
+    no_trailer = on("LZ4F_MI355X_NO_TRAILER"); no_density_probe = on("LZ4F_MI355X_NO_DENSITY_PROBE"); no_spx = on("LZ4F_MI355X_NO_SPX"); no_overlap = on("LZ4F_MI355X_NO_OVERLAP"); no_content_check = on("LZ4F_MI355X_NO_CONTENT_CHECK"); prof = on("LZ4F_MI355X_PROF"); e1_sync = on("LZ4F_MI355X_E1_SYNC"); no_selffeed = on("LZ4F_MI355X_NO_SELFFEED");
     chain_gate = 0; if (const char* v = getenv("LZ4F_MI355X_CHAIN_GATE")) { const int g = atoi(v); if (g > 0 && g < (1 << 20)) chain_gate = g; }
     decode_mode = 0; if (const char* v = getenv("LZ4F_MI355X_DECODE")) decode_mode = v[0];
     e1_run = 0; if (const char* v = getenv("LZ4F_MI355X_E1_RUN")) { const int g = atoi(v); if (g >= 1 && g <= 4096) e1_run = (unsigned)g; }
@@ -210,14 +210,16 @@ size_t lz4f_mi355x_engine::sync()
 static unsigned long long* g_prof = nullptr;
 static unsigned long long* prof_buf()
 {
-    if (!g_prof) { if (hipMalloc(&g_prof, 1024) != hipSuccess) return nullptr; (void)hipMemset(g_prof, 0, 1024); }
+    if (!g_prof) { if (hipMalloc(&g_prof, 1024) != hipSuccess) return nullptr; (void)hipMemset(g_prof, 0, 1024); (void)hipMemset(g_prof + 70, 0xFF, 8); (void)hipMemset(g_prof + 75, 0xFF, 8); }
     return g_prof;
 }
 extern "C" __attribute__((visibility("default"))) int lz4f_mi355x_debug_prof(unsigned long long* out128)
 {
     if (!g_prof) return 1;
     (void)hipDeviceSynchronize();
-    return hipMemcpy(out128, g_prof, 1024, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+    const int rc = hipMemcpy(out128, g_prof, 1024, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+    (void)hipMemset(g_prof, 0, 1024); (void)hipMemset(g_prof + 70, 0xFF, 8); (void)hipMemset(g_prof + 75, 0xFF, 8);      // (the grid-wide words accumulate: start again)
+    return rc;
 }
 
 // The record pool of one compress call, in records: `per_tile` a 64 KiB tile on average (0 = the default, 12288: a sequence per 5.3 input
@@ -625,6 +627,35 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 hipLaunchKernelGGL(k_check_index, dim3(1), dim3(64), 0, st, (const void*)d_index, (uint64_t)index_size, n_ix, cpb, chunk,
                                    (uint64_t)ix_seq_cap, (uint32_t*)seqcnt.p, (const ResultRec*)d_res);
                 uint32_t n_lanes = ix_entries_hint > n_ix ? ix_entries_hint : n_ix;           // (grid-stride inside: a hint is enough)
+                // Independent blocks that are not dense (no tracer on offer): ONE kernel - the copy workgroup's first wave parses its block's
+                // runs and resolves direct matches while the copiers move bytes (decode_indexed.cuh: k_copy_selffed)
+                const bool can_double0 = ((uint64_t)ix_seqs * 48 > (uint64_t)n_ix * j.block_size || sw.trace_always) && (uint64_t)n_ix * j.block_size <= IXP_MAX_SPAN && !sw.no_doubling;
+                const bool selffeed = !j.linked && !sw.no_selffeed && !sw.no_resolve && !sw.trace_always && !can_double0;
+                if (selffeed) {
+                    tick(8, true);
+                    tick(9, false);
+                    if (spx_mode) {
+                        const FzSrcSpx src{(const SpxPoint*)spx.p, (const uint32_t*)((const uint8_t*)spx.p + (size_t)n_max * (SPX_MAXSEG + 1) * sizeof(SpxPoint))};
+                        if (j.block_size <= (1u << 20))
+                            hipLaunchKernelGGL((k_copy_selffed<FzCfgS4, FzSrcSpx>), dim3(n_ix), dim3(64 * 4), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, tbl, (const ResultRec*)d_res, n_ix,
+                                               (const void*)d_index, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, iprof, src);
+                        else
+                            hipLaunchKernelGGL((k_copy_selffed<FzCfgS8, FzSrcSpx>), dim3(n_ix), dim3(64 * 8), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, tbl, (const ResultRec*)d_res, n_ix,
+                                               (const void*)d_index, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, iprof, src);
+                    } else {
+                        const FzSrcIx src{(const void*)d_index, n_ix};
+                        if (j.block_size <= (1u << 20))
+                            hipLaunchKernelGGL((k_copy_selffed<FzCfgS4, FzSrcIx>), dim3(n_ix), dim3(64 * 4), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, tbl, (const ResultRec*)d_res, n_ix,
+                                               (const void*)d_index, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, iprof, src);
+                        else
+                            hipLaunchKernelGGL((k_copy_selffed<FzCfgS8, FzSrcIx>), dim3(n_ix), dim3(64 * 8), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, tbl, (const ResultRec*)d_res, n_ix,
+                                               (const void*)d_index, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, iprof, src);
+                    }
+                    tick(9, true);
+                    indexed = true;
+                    ix_flags = (const uint32_t*)seqcnt.p;
+                    plan |= LZ4F_MI355X_PATH_INDEXED;
+                } else {
                 if (spx_mode)                                                                 // (no entries: the stretches between the blocks' check lines)
                     hipLaunchKernelGGL(k_spx_parse, dim3(n_ix), dim3(128), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl, (const ResultRec*)d_res, n_ix,
                                        (const void*)d_index, (const SpxPoint*)spx.p, (const uint32_t*)((const uint8_t*)spx.p + (size_t)n_max * (SPX_MAXSEG + 1) * sizeof(SpxPoint)),
@@ -706,6 +737,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 indexed = true;
                 ix_flags = (const uint32_t*)seqcnt.p;
                 plan |= LZ4F_MI355X_PATH_INDEXED;
+                }
             }
         }
         if (mode == 'f') {
