@@ -134,6 +134,12 @@ __device__ __forceinline__ int32_t wave_decode_block(const uint8_t* __restrict__
 // offset are four v_readlane and a funnel shift instead of scalar loads; short literal runs come out of the window by
 // ds_bpermute; the next window is on its way while this one is parsed).  Same accept/reject rules as wave_decode_block.
 //   readable: bytes that may be read from `in` on (the frame's end), >= csize
+#ifdef DB_PROF      // development: cycle stamps of the lanes' path, summed over the grid's first waves (tools/cfg2_prof.py)
+__device__ unsigned long long g_dbprof[16];
+#define DBP(...) __VA_ARGS__
+#else
+#define DBP(...)
+#endif
 template <bool VEC>
 __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable,
                                                          uint8_t* out, uint32_t cap, uint32_t* expand /* 64 words of LDS, this wave's */)
@@ -185,6 +191,7 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
         }
     };
     uint32_t pos = 0, op = 0;
+    DBP(unsigned long long a_top = 0, a_parse = 0, a_lit = 0, a_rounds = 0, a_ord = 0, a_seq = 0, n_win = 0, n_round = 0, n_ord = 0, n_seq = 0;)
     uint32_t dnext = 0, dnext_pos = NONE;                                    // the lanes' path: the next window's bytes, asked for ahead of time
     // one sequence on the scalar unit.  0: go on, 1: that was the last one, -1: malformed
     auto one_sequence = [&]() -> int {
@@ -244,7 +251,9 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
         // last one or run into the end-of-block rules)
         if (VEC && pos <= csize && csize - pos >= 96u && cap - op >= 1024u) {
             typedef uint32_t u32_ua1 __attribute__((aligned(1)));
+            DBP(const unsigned long long y0 = clock64();)
             const uint32_t d = dnext_pos == pos ? dnext : *(const u32_ua1*)(in + pos + lane);
+            DBP(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); const unsigned long long y1 = clock64(); a_top += y1 - y0;)
             // (a literal length of 15..269 - one extension byte - is still a lane's own business: the byte is in its dword.  Longer
             // ones, and tokens with match-length bytes, go to one_sequence.)
             const uint32_t t = d & 0xFFu, litn = t >> 4, ml = t & 15u, e1 = (d >> 8) & 0xFFu;
@@ -276,6 +285,7 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
                 const uint32_t both = dpp_incl_scan_add(tout | (mcnt << 16));
                 const uint32_t incl = both & 0xFFFFu, ex = incl - tout, mincl = both >> 16, mex = mincl - mcnt;
                 const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                DBP(const unsigned long long y2 = clock64(); a_parse += y2 - y1; n_win++;)
                 const uint32_t mdst = op + ex + lit;                         // where the token's match goes
                 if (__ballot(is_tok && (off == 0u || off > mdst))) return -1;
                 // literals: byte lane l belongs to the nearest token at or below it
@@ -287,6 +297,7 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
                 // lane per byte - a prefix sum places every match in that space, its lane leaves its number at the start of its run
                 // (`expand`, 64 words of LDS), a running maximum spreads it over the run.  A match whose source reaches into this
                 // window's own matches waits for the ordered loop behind.
+                DBP(const unsigned long long y3 = clock64(); a_lit += y3 - y2;)
                 const uint32_t mtotal = (uint32_t)__builtin_amdgcn_readlane((int)mincl, 63);
                 const uint32_t md0 = (uint32_t)__builtin_amdgcn_readlane((int)mdst, 0);          // the window's first match: everything in front of it is stored or on its way
                 const bool indep = is_tok && mdst - off + mlen <= md0;                          // (implies off >= mlen: no overlap with itself either)
@@ -309,7 +320,9 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
                     const uint32_t bi = lane - (pb >> 16), bd = pa & 0xFFFFFFu;                // my byte within the match, the match's destination
                     if (k1 && bi < (pa >> 24)) { const uint8_t b = out[bd - (pb & 0xFFFFu) + bi]; out[bd + bi] = b; }
                     base = nbase;
+                    DBP(n_round++;)
                 }
+                DBP(const unsigned long long y4 = clock64(); a_rounds += y4 - y3;)
                 const bool together = indep && mex < base;                      // (copied by the rounds above)
                 uint64_t m = __ballot(is_tok && !together);                                    // the others, in order
                 while (m) {
@@ -320,13 +333,18 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
                     uint32_t idx = lane;
                     if (ok < lk) idx = lane % ok;                            // (overlapping: repeats its period; lk <= 18)
                     if (lane < lk) { const uint8_t b = out[dk - ok + idx]; out[dk + lane] = b; }
+                    DBP(n_ord++;)
                 }
+                DBP(a_ord += clock64() - y4;)
                 op += total;
                 pos += s;
                 continue;
             }
         }
+        DBP(const unsigned long long x0 = clock64();)
         const int r = one_sequence();
+        DBP(a_seq += clock64() - x0; n_seq++;)
+        DBP(if (r != 0 && lane == 0 && blockIdx.x < 64) { atomicAdd(&g_dbprof[0], a_top); atomicAdd(&g_dbprof[1], a_parse); atomicAdd(&g_dbprof[2], a_lit); atomicAdd(&g_dbprof[3], a_rounds); atomicAdd(&g_dbprof[4], a_ord); atomicAdd(&g_dbprof[5], a_seq); atomicAdd(&g_dbprof[6], n_win); atomicAdd(&g_dbprof[7], n_round); atomicAdd(&g_dbprof[8], n_ord); atomicAdd(&g_dbprof[9], n_seq); atomicAdd(&g_dbprof[10], 1ull); })
         if (r < 0) return -1;
         if (r > 0) return (int32_t)op;
     }

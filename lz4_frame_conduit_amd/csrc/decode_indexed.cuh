@@ -79,8 +79,8 @@ __global__ void k_check_index(const void* __restrict__ ix, uint64_t ix_size, uin
 // block that a match of a linked frame may reach.
 __device__ __forceinline__ bool parse_run(const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable, uint32_t& pos, uint32_t op, uint32_t my_nseq,
                                           bool is_tail, SeqDesc* __restrict__ out, uint32_t linked, uint64_t out_front,
-                                          uint32_t* opr = nullptr, uint32_t seq0 = 0, uint32_t omask = 0)
-{   // opr: (the feeder that parses for itself, fz_feeder_parse) every sequence's output position also goes into a ring in LDS
+                                          uint32_t* opr = nullptr, uint32_t seq0 = 0, uint32_t omask = 0, uint32_t* op_end = nullptr)
+{   // op_end: where the output stands behind the run's last sequence.  opr: (the feeder that parses for itself, fz_feeder_parse) every sequence's output position also goes into a ring in LDS
     bool bad = false;
     // the last four output ranges whose bytes are known to sit in the payload (literal runs, and matches that copied from such a
     // range): a match that lies inside one is DIRECT -- a plain copy out of the payload that needs no earlier output
@@ -158,6 +158,7 @@ __device__ __forceinline__ bool parse_run(const uint8_t* __restrict__ in, uint32
         if (opr) opr[(seq0 + i) & omask] = op;
         op += lit + mlen;
     }
+    if (op_end) *op_end = op;
     return bad;
 }
 
@@ -1120,7 +1121,11 @@ template <class C, class RUNS>
 __device__ __forceinline__ void fz_feeder_parse(FzShared<C>& sh, const RUNS& runs, const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable,
                                                 SeqDesc* desc, uint32_t nseq, uint32_t cap, unsigned long long* prof)
 {
+#ifdef FZ_TEST_ROUND      // development: a round so small that every stretch of a foreign frame goes in pieces (the `part` path below)
+    constexpr uint32_t OPR = FzOpr<C>::N, OMASK = OPR - 1, ROUND_MAX = FZ_TEST_ROUND;
+#else
     constexpr uint32_t OPR = FzOpr<C>::N, OMASK = OPR - 1, ROUND_MAX = OPR / 2;
+#endif
     unsigned long long t_parse = 0, t_res = 0, t_ring = 0, n_round = 0, t_load = 0;
     const unsigned long long t_begin = clock64();
     uint32_t* opr = (uint32_t*)&sh.stage[0][0];
@@ -1131,6 +1136,7 @@ __device__ __forceinline__ void fz_feeder_parse(FzShared<C>& sh, const RUNS& run
     uint32_t expect = 0, status = nseq ? 0u : 1u, published = 0;
     uint32_t W = 0, u0 = 0;                                                  // sequences parsed so far (descriptors in HBM, positions in the ring); next run
     uint4 nxt = {0u, 0u, 0u, 0u}; bool nxt_ok = false;
+    uint32_t part_left = 0, part_pos = 0, part_out = 0;                      // a run that goes in pieces: sequences left of it, where its next piece starts
     for (uint32_t slot = 0; slot < nslots && !status; slot++) {
         const uint32_t first = slot * per;
         const uint32_t count = (nseq - first < per) ? nseq - first : per;
@@ -1142,20 +1148,29 @@ __device__ __forceinline__ void fz_feeder_parse(FzShared<C>& sh, const RUNS& run
             const bool have = u0 + lane < nruns;
             FzRun r{0u, 0u, 0u, 0u, 0u, false, false};
             if (have) r = runs.get(u0 + lane);
+            // (a run of more sequences than a round may hold - a stretch of a foreign frame's payload with short sequences, or one the
+            // stitching thread walked itself - goes in pieces: lane 0 takes the next ROUND_MAX of it, alone, and the rest waits in `part`)
+            if (part_left && lane == 0) { r.in_off = part_pos; r.out_pos = part_out; r.seq_off = W; r.nseq = part_left; }
+            const uint32_t whole0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.nseq);
+            const bool cut = whole0 > ROUND_MAX;                             // (wave-uniform)
+            if (cut && lane == 0) r.nseq = ROUND_MAX;
             uint32_t tot;
             const uint32_t before = wave_excl_scan(have ? r.nseq : 0u, tot);
-            const uint64_t refused = __ballot(have && lane != 0 && before + r.nseq > ROUND_MAX), hv = __ballot(have);
+            const uint64_t refused = __ballot(have && lane != 0 && (cut || before + r.nseq > ROUND_MAX)), hv = __ballot(have);
             const uint32_t R = refused ? (uint32_t)__builtin_ctzll(refused) : (uint32_t)__builtin_popcountll(hv);      // (a prefix of the lanes)
             const bool mine = lane < R;
             bool bad = mine && (r.bad || r.nseq > ROUND_MAX || (lane == 0 && r.seq_off != W));
-            uint32_t pos = r.in_off;
+            uint32_t pos = r.in_off, op_end = 0;
             if (mine && !bad) {
-                bad = parse_run(in, csize, readable, pos, r.out_pos, r.nseq, r.tail, desc + r.seq_off, 0u, 0ull, opr, r.seq_off, OMASK);
-                bad |= pos != r.stop;                                        // must end exactly where the next run starts
+                bad = parse_run(in, csize, readable, pos, r.out_pos, r.nseq, r.tail && !(cut && lane == 0), desc + r.seq_off, 0u, 0ull, opr, r.seq_off, OMASK, &op_end);
+                if (!(cut && lane == 0)) bad |= pos != r.stop;               // must end exactly where the next run starts
             }
             if (__ballot(bad)) { status = 1; break; }
             W = (uint32_t)__builtin_amdgcn_readlane((int)(r.seq_off + r.nseq), (int)(R - 1));
-            u0 += R;
+            if (cut) {                                                       // (R == 1: the run stays the next one until all of it is parsed)
+                part_left = whole0 - ROUND_MAX;
+                part_pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)pos); part_out = (uint32_t)__builtin_amdgcn_readfirstlane((int)op_end);
+            } else { part_left = 0; u0 += R; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
         if (status) break;

@@ -215,9 +215,12 @@ static unsigned long long* prof_buf()
 }
 extern "C" __attribute__((visibility("default"))) int lz4f_mi355x_debug_prof(unsigned long long* out128)
 {
-    if (!g_prof) return 1;
+    if (!prof_buf()) return 1;
     (void)hipDeviceSynchronize();
     const int rc = hipMemcpy(out128, g_prof, 1024, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
+#ifdef DB_PROF
+    { unsigned long long z[16] = {0}; (void)hipMemcpyFromSymbol(out128 + 96, HIP_SYMBOL(lz4f::g_dbprof), sizeof(z)); (void)hipMemcpyToSymbol(HIP_SYMBOL(lz4f::g_dbprof), z, sizeof(z)); }
+#endif
     (void)hipMemset(g_prof, 0, 1024); (void)hipMemset(g_prof + 70, 0xFF, 8); (void)hipMemset(g_prof + 75, 0xFF, 8);      // (the grid-wide words accumulate: start again)
     return rc;
 }
@@ -268,7 +271,9 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
     g.seed_stride = sw.seed;
 
     if (info.ensure((size_t)(g.n_chunks + 1) * sizeof(ChunkInfo))) return make_err(LZ4F_ERROR_allocation_failed);
-    g.rec_pool = rec_pool_records(g.n_chunks, g.max_rec_per_chunk, sw.recs_per_tile);
+    // (deterministic mode: the worst case for every tile - which tiles a short pool turns away is a matter of which workgroup's merge
+    // gets to the bump pointer first, and "equal input, equal bytes" must not hang on that: 2 bytes of workspace per input byte)
+    g.rec_pool = rec_pool_records(g.n_chunks, g.max_rec_per_chunk, (sw.e1_solo & 1u) ? 16385u : sw.recs_per_tile);
     if (recs.ensure((size_t)(rec_pool_at(g.n_chunks) + g.rec_pool) * 8)) return make_err(LZ4F_ERROR_allocation_failed);
     if (blk_bytes.ensure((size_t)(g.n_blocks + 1) * 4)) return make_err(LZ4F_ERROR_allocation_failed);
     if (!d_table) { if (table.ensure((size_t)(g.n_blocks + 1) * sizeof(BlockOut))) return make_err(LZ4F_ERROR_allocation_failed); d_table = (lz4f_mi355x_block*)table.p; }

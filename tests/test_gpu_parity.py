@@ -627,11 +627,15 @@ def _indexed_inputs():
     yield "tiny", np.frombuffer(b"hello hello hello hello hello hello hello hello", dtype=np.uint8).copy()
 
 
-def test_indexed_decode_same_bytes_as_generic(L):
+@pytest.mark.parametrize("selffeed", [True, False])
+def test_indexed_decode_same_bytes_as_generic(L, monkeypatch, selffeed):
     """The compressor's sequence index only tells the decoder where it may start parsing: with it (indexed kernels) and
-    without it (generic kernels) the same frame gives the same bytes, for every block size the indexed path takes."""
+    without it (generic kernels) the same frame gives the same bytes, for every block size the indexed path takes.
+    Independent blocks go through the self-feeding copy kernel (k_copy_selffed: the workgroup's first wave parses and resolves);
+    selffeed = False: through k_parse_indexed / k_resolve_direct / k_copy_indexed as linked and dense frames do."""
     import torch
     from lz4_frame_conduit_amd.device import Engine
+    if not selffeed: monkeypatch.setenv("LZ4F_MI355X_NO_SELFFEED", "1")         # (switches are read when an engine is made)
     eng = Engine(0)
     used = 0
     for name, data in _indexed_inputs():
@@ -1119,6 +1123,34 @@ def test_deterministic_encoder_mode(L):
             assert used == len(host) and out == data.tobytes(), (name, kw)
             ref = oracle.conduit_compress(data.tobytes(), oracle.mkprefs(**kw))
             assert len(host) <= len(ref) * (1.32 if name == "structured" else RATIO_TOL), (name, kw, len(host), len(ref))      # (structured: the stress inputs' own bound, see test_structured_inputs_both_directions)
+    # a record pool set too small for dense input (LZ4F_MI355X_RECS_PER_TILE) must not make the bytes a matter of which tile asked first:
+    # the deterministic mode sizes the pool for the worst case itself
+    import os
+    os.environ["LZ4F_MI355X_RECS_PER_TILE"] = "512"
+    try:
+        data = inputs["text"]; src = torch.from_numpy(data.copy()).cuda(); p = prefs_of(dict(bsid=7, indep=1)); seen = set()
+        for attempt in range(3):
+            eng = Engine(0); eng.set_deterministic(True)
+            frame = torch.zeros(eng.frame_bound(src.numel(), p), dtype=torch.uint8, device="cuda")
+            eng.compress_async(src, frame, p); r = eng.result()
+            assert not (int(r.flags) & 0x200), "tiles went out as literals in deterministic mode"
+            seen.add(sha(frame[:r.size].cpu().numpy().tobytes())); eng.close()
+        assert len(seen) == 1
+    finally:
+        os.environ.pop("LZ4F_MI355X_RECS_PER_TILE", None)
+
+
+def _short_sequences(n: int, seed: int) -> np.ndarray:
+    """34 random bytes, then a copy of 30 bytes from 0.1..3 KiB back (inside what liblz4's 4096-entry table still knows), and so on: ~30 payload bytes per sequence - sparse by the density probe's
+    rule (>= 24), and more than a thousand sequences in a 32 KiB stretch of payload: the self-feeding copy kernel takes such a stretch in pieces."""
+    rng = np.random.default_rng(seed)
+    out = rng.integers(0, 256, n, dtype=np.uint8)
+    pos = 65536
+    while pos + 64 <= n:
+        back = int(rng.integers(100, 3000))
+        out[pos + 34:pos + 64] = out[pos + 34 - back:pos + 64 - back]
+        pos += 64
+    return out
 
 
 @pytest.mark.gpu
@@ -1142,13 +1174,14 @@ def test_foreign_big_independent_blocks_stretch_parallel(L):
         "ints": np.frombuffer(datagen.ints_100000() * 9, dtype=np.uint8),
         "one short block": s50[:300000],
         "tiny": s50[:13],
+        "short sequences": _short_sequences(6 << 20, 21),
     }
     frames = []
     for name, data in inputs.items():
         for kw in (dict(bsid=7, indep=1), dict(bsid=6, indep=1, bck=1), dict(bsid=5, indep=1, cck=1)):
             frames.append((name, kw, data, oracle.conduit_compress(data.tobytes(), oracle.mkprefs(**kw))))
     import os
-    for env in ({}, {"LZ4F_MI355X_NO_SPX": "1"}):
+    for env in ({}, {"LZ4F_MI355X_NO_SELFFEED": "1"}, {"LZ4F_MI355X_NO_SPX": "1"}):
         os.environ.update(env)
         L.lz4f_mi355x_release_engines()
         try:
@@ -1163,7 +1196,7 @@ def test_foreign_big_independent_blocks_stretch_parallel(L):
                 assert r.size == len(data) and r.consumed == len(fr) and back[:len(data)].cpu().numpy().tobytes() == data.tobytes(), (name, kw, env)
                 path = int(r.flags) >> 12
                 if name in ("synth50+tail", "stored inside") and kw["bsid"] >= 6:
-                    want = 0 if env else PATH["self_index"] | PATH["indexed"]
+                    want = 0 if "LZ4F_MI355X_NO_SPX" in env else PATH["self_index"] | PATH["indexed"]
                     assert path & (PATH["self_index"] | PATH["indexed"] | PATH["dropped"]) == want, (name, kw, env, hex(path))
             eng.close()
         finally:
