@@ -173,6 +173,13 @@ static_assert(64 * E1_WAVES >= E1_NSLICE, "a thread per slice when the lists are
 #ifndef E1_OPENER
 #define E1_OPENER 2
 #endif
+#ifndef E1_ALIGN
+#define E1_ALIGN 1
+#endif
+// the stride the search goes on with behind a match where sequences are long (liblz4 starts again at 1)
+#ifndef E1_STEP_HIT
+#define E1_STEP_HIT 1
+#endif
 constexpr uint32_t E1_GRAB_SPARSE = E1_GRAB, E1_GRAB_DENSE = E1_GRAB_D, E1_PROBE_SLICES = 16, E1_DENSE_HITS = 24;
 
 // 4 / 8 bytes at any byte position of the ring.  (A byte-unaligned ds_read_b32 / _b64 is legal on gfx950 but keeps the LDS busy
@@ -442,7 +449,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
         }
     };
 
-    if (tid == 0) { sh.mode = 0; sh.cov = E1_TILE; sh.hits = 0; sh.first = 0; sh.next = 1; sh.pieces[0] = 0; sh.pieces[1] = 0; sh.tail_d[0] = 0; sh.tail_d[1] = 0; }
+    if (tid == 0) { sh.mode = 0; sh.cov = E1_TILE; sh.hits = 0; sh.first = 0; sh.next = E1_ALIGN ? 0 : 1; sh.pieces[0] = 0; sh.pieces[1] = 0; sh.tail_d[0] = 0; sh.tail_d[1] = 0; }
     if (tid < 16) sh.cur[tid] = 0;
     uint32_t mode_tile = 0;                                              // (deterministic parse) sh.mode as it stood when this tile began
     uint32_t hold = 1;                                                   // this tile's first slice is waited for: the tile before was left inside a match that goes on
@@ -509,11 +516,15 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
             // going ahead without it costs ratio, nothing else).  Where the tile begins inside a long or periodic match - one hot
             // table slot per distinct four bytes, always holding a position of whoever is furthest ahead - that slice finds it,
             // publishes its end, and nobody searches what it covers.
-            const bool opener = fresh && wave == 0;
+            // (E1_ALIGN, round 4: only a tile that is waited for has an opener.  Otherwise the first wave takes a helping like everybody - the
+            // helpings then start at multiples of their size instead of one slice behind: on the bench input, rows of 512 bytes, a helping
+            // began 128 bytes into a random row and ended 128 bytes into the next one, which cost a second probe step per helping, at stride 1)
+            const bool opener = fresh && wave == 0 && (!E1_ALIGN || hold);
             const uint32_t grab = opener ? 1u : mode == 1 ? E1_GRAB_SPARSE : mode == 2 ? E1_GRAB_DENSE : 1u;
             uint32_t si = 0;
+            if (E1_ALIGN && opener) si = uni(atomicAdd(lane == 0 ? &sh.next : &sh.idle[lane], grab));      // (the others wait for sh.first: this is slice 0)
             if (!opener) {
-                if (fresh && E1_OPENER && (E1_OPENER == 1 || hold)) for (uint32_t spin = 0; spin < 4096 && uni(__hip_atomic_load(&sh.first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0; spin++) __builtin_amdgcn_s_sleep(2);
+                if (fresh && E1_OPENER && ((E1_OPENER == 1 && !E1_ALIGN) || hold)) for (uint32_t spin = 0; spin < 4096 && uni(__hip_atomic_load(&sh.first, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) == 0; spin++) __builtin_amdgcn_s_sleep(2);
                 si = uni(atomicAdd(lane == 0 ? &sh.next : &sh.idle[lane], grab));
             }
             fresh = false;
@@ -779,7 +790,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
                     myrec[nrec] = pack_rec(mp - anchor, mlen, d);              // (every lane stores the same 8 bytes)
                     nrec++;
                     anchor = ip = mp + mlen;
-                    step = 1; two = 1;
+                    step = (E1_STEP_HIT > 1 && mode == 1) ? (uint32_t)E1_STEP_HIT : 1u; two = 1;
                     atomicMax(lane == 0 ? &sh.cov : &sh.idle[lane], ip);
                     if (E1_OPENER == 2) *((lane == 0 && ip == end_lim) ? &sh.tail_d[par] : &sh.idle[lane]) = d;      // (cut at the tile's end: the next tile's first slice may find the rest)
                     // like the CPU encoder, also index ip - 2
@@ -802,7 +813,7 @@ __global__ __launch_bounds__(64 * E1_WAVES) void k_find_matches(const uint8_t* _
         pend = true; p_c = c; p_par = par; p_ts = ts; p_te = te; p_bend = bend; p_ns = nslice;
 
         // ---- what is left of the next tile into the ring; counters for it ----
-        if (tid == 0) { sh.tail_d[par ^ 1u] = 0; sh.cov = nts; sh.hits = 0; sh.first = 0; sh.next = 1; sh.pieces[par ^ 1u] = 0; }      // (slice 0 is the first wave's)
+        if (tid == 0) { sh.tail_d[par ^ 1u] = 0; sh.cov = nts; sh.hits = 0; sh.first = 0; sh.next = E1_ALIGN ? 0 : 1; sh.pieces[par ^ 1u] = 0; }      // (E1_ALIGN 0: slice 0 is the first wave's)
         if (tid < 16) sh.cur[tid] = 0;
         if (nlen) {
             if (nlen_full) {
