@@ -49,7 +49,7 @@ GIB = float(1 << 30)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 HBM_COPY_GBS = 6290.0
 PCIE_GBS = 63.0                # MI355X_MICROARCH.md: PCIe Gen5 x16, 63 GB/s spec (53-54 GiB/s measured each way, tools/probe/pcie_rates.py)
-PMC_PROFILE = "profiles/round3_pmc_traffic.json"
+PMC_PROFILE = "profiles/round4_pmc_traffic.json"
 
 
 def pmc_traffic(kernel: str, n_bytes: int, block_size: int):
@@ -564,7 +564,7 @@ def main():
                 d = kernels["decode"]["algo_GBs"]
                 out["roofline_decode"] = {"bound": "hbm", "achieved": d, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(d / HBM_PEAK_GBS, 4),
                                           "traffic": pmc_traffic("decode", n, bs),
-                                          "kernels": "k_check_index + k_parse_indexed + k_resolve_direct + k_copy_indexed (+ the trailer's link check in `walk`)" if inband else "k_decode_blocks_fused"}
+                                          "kernels": "k_check_index + k_copy_selffed (the copy workgroup's first wave parses and resolves; + the trailer's link check in `walk`)" if inband else "k_decode_blocks_fused"}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(bs, args.cpu_sample_mib << 20)

@@ -16,7 +16,7 @@ for f in glob.glob(f"{R}/gpurun_out/prof_{TAG}_sq/**/*counter_collection.csv", r
         if not k.startswith("k_"): continue
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
 out = {k: {c: acc[k][c] / cnt[k][c] for c in acc[k]} for k in acc}
-json.dump({"note": "rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR around bench.py --headline-only; per-launch means (wave instructions)", "kernels": out}, open(f"{R}/gpurun_out/{TAG}_sq.json", "w"), indent=1)
+json.dump({"git_head": __import__("os").environ.get("GIT_HEAD", "unknown"), "note": "rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR around bench.py --headline-only; per-launch means (wave instructions)", "kernels": out}, open(f"{R}/gpurun_out/{TAG}_sq.json", "w"), indent=1)
 for k in ("k_find_matches", "k_emit_gather<4>", "k_copy_indexed<FzCfg<8> >", "k_parse_indexed"):
     if k in out: print(k, {c: round(v / 1e6, 1) for c, v in out[k].items()}, "M")
 PY

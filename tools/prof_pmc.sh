@@ -25,7 +25,7 @@ out = {k: dict({c: acc[k][c] / cnt[k][c] for c in sorted(acc[k])}, launches_seen
 for k, v in out.items():
     if "FETCH_SIZE" in v or "WRITE_SIZE" in v:
         v["hbm_bytes_corrected"] = int(2 * v.get("FETCH_SIZE", 0.0) * 1024 + v.get("WRITE_SIZE", 0.0) * 1024)
-json.dump({"note": "rocprofv3 --pmc (four passes: SQ waits, SQ instruction counts + LDS, FETCH_SIZE, WRITE_SIZE; --kernel-trace only) around bench.py %s; per-launch means over ALL launches of a kernel in the run "
+json.dump({"git_head": __import__("os").environ.get("GIT_HEAD", "unknown"), "note": "rocprofv3 --pmc (four passes: SQ waits, SQ instruction counts + LDS, FETCH_SIZE, WRITE_SIZE; --kernel-trace only) around bench.py %s; per-launch means over ALL launches of a kernel in the run "
                    "(the headline's launches included).  FETCH_SIZE / WRITE_SIZE in KiB; hbm_bytes_corrected = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH.md: FETCH_SIZE reads half of wide coalesced reads on gfx950)" % "$*",
            "kernels": out}, open(f"{R}/gpurun_out/{TAG}_pmc.json", "w"), indent=1)
 for k in sorted(out, key=lambda k: -out[k].get("SQ_WAVE_CYCLES", 0))[:8]:

@@ -35,8 +35,8 @@ for k in sorted(set(fe) | set(wr)):
     f_raw = fe.get(k, 0.0) * 1024; w_b = wr.get(k, 0.0) * 1024
     kernels[k] = {"fetch_bytes_raw": int(f_raw), "fetch_bytes_x2": int(2 * f_raw), "write_bytes": int(w_b), "hbm_bytes_corrected": int(2 * f_raw + w_b)}
 groups = {"find_matches": [k for k in kernels if k.startswith("k_find_matches")], "emit": [k for k in kernels if k.startswith("k_emit_gather")],
-          "decode": [k for k in kernels if k.split("<")[0] in ("k_check_index", "k_parse_indexed", "k_resolve_direct", "k_copy_indexed", "k_dense_gate", "k_finish_decode")]}
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around `python3 bench.py --headline-only --steps 4 --warmup 2 --no-cpu-baseline`; "
+          "decode": [k for k in kernels if k.split("<")[0] in ("k_check_index", "k_parse_indexed", "k_resolve_direct", "k_copy_indexed", "k_copy_selffed", "k_dense_gate", "k_finish_decode")]}
+json.dump({"git_head": os.environ.get("GIT_HEAD", "unknown"), "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) around `python3 bench.py --headline-only --steps 4 --warmup 2 --no-cpu-baseline`; "
                    "per-launch means.  Units: FETCH_SIZE/WRITE_SIZE are KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reads exactly 1/2 of the bytes of wide (16 B/lane) "
                    "coalesced streaming reads -> read_bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact for 16 B/lane stores.  k_find_matches reads its input by LDS-DMA, 16 B per lane (the calibrated shape).",
            "workload": "4 GiB synth50, 4 MiB independent blocks, 1 GPU, decode from the stream alone (in-band trailer)", "kernels": kernels, "groups": groups},
