@@ -38,6 +38,8 @@ constexpr uint32_t SPX_SEG = 32768, SPX_SCAN = 8192, SPX_CAND = 6, SPX_MAXSEG = 
 constexpr uint32_t SPX_LANE_HOPS = 2048;                        // sequences a lane follows before it gives its stretch up (sparse payloads: >= 24 bytes per sequence, 1400 per stretch)
 constexpr uint32_t SPX_RESCUE = 1u << 16;                       // sequences the stitching thread may walk itself per block before it gives up
 constexpr uint32_t SPX_NONE = 0xFFFFFFFFu;
+constexpr uint32_t SPX_SUB = 8, SPX_SUB_STRIDE = 16;            // round 4: a lane also notes where it stands every 16 sequences (a stride that doubles when its eight places are full) - see k_spx_index
+constexpr uint32_t SPX_MAXPT = SPX_MAXSEG * (SPX_SUB + 1);      // points per block: every stretch's start and what its lane noted on the way
 struct SpxPoint { uint32_t pos, seq, out; };                    // a token position of the block's payload, the number of the sequence that starts there, its output position
 
 // One sequence of the payload in[0, csize) at c.pos: lengths only (the walk that finds out WHERE sequences are; parse_run checks
@@ -102,7 +104,7 @@ __device__ __forceinline__ bool spx_likely_token(const uint8_t* __restrict__ in,
 }
 
 // ---- k_spx_index: a workgroup per block ----
-// T (SPX_MAXSEG + 1 points per block): T[k] = where stretch k starts (k = 0: byte 0), T[stretches] = the payload's end; nr[b]: stretches.
+// T (SPX_MAXPT + 1 points per block): T[k] = where run k starts (k = 0: byte 0) - a stretch's start, or what its lane noted on the way -, T[runs] = the payload's end; nr[b]: runs.
 __global__ __launch_bounds__(128) void k_spx_index(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
                                                    const ResultRec* __restrict__ res, uint32_t n_max, uint32_t* __restrict__ cnt, uint32_t* __restrict__ osz,
                                                    SpxPoint* __restrict__ T, uint32_t* __restrict__ nr, uint32_t* __restrict__ flags,
@@ -112,6 +114,13 @@ __global__ __launch_bounds__(128) void k_spx_index(const uint8_t* __restrict__ f
     __shared__ uint32_t s_cand[SPX_MAXSEG][SPX_CAND], s_ncand[SPX_MAXSEG];      // per lane: the first pairs of its segment
     __shared__ SpxPoint s_b[SPX_MAXSEG];                        // per lane: where its chain lands at or behind the NEXT lane's start (counts relative to its own start); pos SPX_NONE: nowhere
     __shared__ uint32_t s_end[SPX_MAXSEG];                      // per lane: 1 = s_b is the payload's end (pos == csize: the counts include the last sequence)
+    // Round 4: the runs the copy kernel's first wave parses (k_copy_selffed) are as long as its chain of dependent loads, and a stretch of 32 KiB is 63 sequences
+    // on the bench frame: a lane notes where it stands every SPX_SUB_STRIDE sequences (counts relative to its own start, like s_b), up to SPX_SUB places - when they
+    // are full every other one goes and the stride doubles - and a true lane's notes become points of their own behind the stitch.
+    __shared__ SpxPoint s_sub[SPX_MAXSEG][SPX_SUB];
+    __shared__ uint32_t s_nsub[SPX_MAXSEG];
+    __shared__ uint32_t s_tidx[SPX_MAXSEG], s_bseq[SPX_MAXSEG], s_bout[SPX_MAXSEG];      // behind the stitch, per lane: where its points go (SPX_NONE: not a true lane), the true counts at its start
+    __shared__ uint32_t s_fail;
     if (res->status != ST_OK) return;
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
     const uint32_t b = blockIdx.x, u = threadIdx.x;
@@ -190,7 +199,7 @@ __global__ __launch_bounds__(128) void k_spx_index(const uint8_t* __restrict__ f
 #endif
     if (u < nl) {
         SpxPoint pb{SPX_NONE, 0, 0};
-        uint32_t ended = 0;
+        uint32_t ended = 0, nsub = 0;
         if (s_g[u] != SPX_NONE) {
             uint32_t stop = SPX_NONE;                                        // the next lane that has a start (none: this lane walks to the end)
             for (uint32_t k = u + 1; k < nl; k++) if (s_g[k] != SPX_NONE && s_g[k] > s_g[u]) { stop = s_g[k]; break; }
@@ -207,9 +216,13 @@ __global__ __launch_bounds__(128) void k_spx_index(const uint8_t* __restrict__ f
             // the stretch.
             const uint32_t slow = (u && s_g[u] == u * SPX_SEG && only_if) ? only_if[1] / 8u : 0u;
             const bool by_pair = u && s_g[u] != u * SPX_SEG;
-            uint32_t longs = 0;
+            uint32_t longs = 0, sub_stride = SPX_SUB_STRIDE;
             for (uint32_t hops = 0;; hops++) {
                 if (c.pos >= stop) { pb = SpxPoint{c.pos, c.seq, c.out}; break; }
+                if (hops && hops % sub_stride == 0) {                        // (c.seq == hops: a token, its number and the output in front of it, all from my start)
+                    if (nsub == SPX_SUB) { for (uint32_t i = 0; i < SPX_SUB / 2; i++) s_sub[u][i] = s_sub[u][2 * i + 1]; nsub = SPX_SUB / 2; sub_stride *= 2; }
+                    if (hops % sub_stride == 0) s_sub[u][nsub++] = SpxPoint{c.pos, c.seq, c.out};
+                }
                 if ((hops & 63u) == 63u) {
                     if (slow && c.pos - s_g[u] < hops * slow) break;
                     if (by_pair && longs * 2u < hops) break;
@@ -224,7 +237,7 @@ __global__ __launch_bounds__(128) void k_spx_index(const uint8_t* __restrict__ f
                 if (r == 2) break;                                           // (a guessed chain may run into anything)
             }
         }
-        s_b[u] = pb; s_end[u] = ended;
+        s_b[u] = pb; s_end[u] = ended; s_nsub[u] = pb.pos != SPX_NONE ? nsub : 0u;
 #ifdef SPX_PROF
         if (s_g[u] == SPX_NONE) atomicAdd(&flags[49], 1u);
         else if (u && s_g[u] == u * SPX_SEG) atomicAdd(&flags[50], 1u);
@@ -240,52 +253,67 @@ __global__ __launch_bounds__(128) void k_spx_index(const uint8_t* __restrict__ f
     const unsigned long long z4 = clock64();
     if ((u & 63) == 0) { atomicMax(&flags[40], (uint32_t)(z1 - z0)); atomicMax(&flags[41], (uint32_t)(z3 - z2)); atomicAdd(&flags[44], (uint32_t)((z1 - z0) >> 8)); atomicAdd(&flags[45], (uint32_t)((z3 - z2) >> 8)); }
 #endif
-    if (u != 0) return;
     // ---- the stitch: lane 0 starts at byte 0 and is true; lane k + 1 is true iff the true chain lands exactly on its start.  A lane
     // ---- that is not (a wrong guess) is skipped: the thread walks on from where the true chain stands until it meets a later lane's start.
-    SpxPoint* Tb = T + (size_t)b * (SPX_MAXSEG + 1);
-    uint32_t k = 0, rescue = 0, stretches = 0;
-    bool bad = false;
-    SpxPoint cur{0, 0, 0};                                                   // the true chain: where stretch `stretches` starts
-    uint32_t total_seq = 0, total_out = 0;
-    for (;;) {
-        // lane k starts where the true chain stands (cur.pos == s_g[k]): its walk is the true chain's
-        Tb[stretches++] = cur;
-        SpxPoint nx{SPX_NONE, 0, 0}; uint32_t ended = 0;
-        if (s_b[k].pos != SPX_NONE) { nx = SpxPoint{s_b[k].pos, cur.seq + s_b[k].seq, cur.out + s_b[k].out}; ended = s_end[k]; }
-        else { bad = true; break; }                                          // (a true chain that runs into something: malformed payload)
-        uint32_t kn = k + 1;
-        while (!ended && !(kn < nl && s_g[kn] == nx.pos)) {
-            // the true chain did not land on the next lane's start (or there is none): walk on from where it stands, to the start of
-            // the first lane it meets (or the end); that lane's own walk is the true chain again
-            if (kn < nl && (s_g[kn] == SPX_NONE || s_g[kn] < nx.pos)) { kn++; continue; }      // (a lane without a start, or one whose start lies behind us already)
-            const uint32_t stop = kn < nl ? s_g[kn] : SPX_NONE;
-            atomicAdd(&flags[2], 1u);                                        // (how often: a developer's number, LZ4F_MI355X_PROF prints it)
-            SpxCur c{nx.pos, nx.seq, nx.out, 0, 0};
-            spx_begin(in, readable, c);
-            for (;;) {
-                if (c.pos >= stop) break;
-                if (++rescue > SPX_RESCUE) { bad = true; break; }
-                const int r = spx_step(in, csize, readable, c);
-                if (r == 1) { ended = 1; break; }
-                if (r == 2) { bad = true; break; }
+    SpxPoint* Tb = T + (size_t)b * (SPX_MAXPT + 1);
+    if (u < SPX_MAXSEG) s_tidx[u] = SPX_NONE;
+    if (u == 0) s_fail = 0;
+    __syncthreads();
+    uint32_t tpos = 0, total_seq = 0, total_out = 0;
+    if (u == 0) {
+        uint32_t k = 0, rescue = 0;
+        bool bad = false;
+        SpxPoint cur{0, 0, 0};                                               // the true chain: where the stretch of lane k starts
+        for (;;) {
+            // lane k starts where the true chain stands (cur.pos == s_g[k]): its walk is the true chain's, and so are its notes
+            s_tidx[k] = tpos; s_bseq[k] = cur.seq; s_bout[k] = cur.out;
+            tpos += 1u + s_nsub[k];
+            SpxPoint nx{SPX_NONE, 0, 0}; uint32_t ended = 0;
+            if (s_b[k].pos != SPX_NONE) { nx = SpxPoint{s_b[k].pos, cur.seq + s_b[k].seq, cur.out + s_b[k].out}; ended = s_end[k]; }
+            else { bad = true; break; }                                      // (a true chain that runs into something: malformed payload)
+            uint32_t kn = k + 1;
+            while (!ended && !(kn < nl && s_g[kn] == nx.pos)) {
+                // the true chain did not land on the next lane's start (or there is none): walk on from where it stands, to the start of
+                // the first lane it meets (or the end); that lane's own walk is the true chain again
+                if (kn < nl && (s_g[kn] == SPX_NONE || s_g[kn] < nx.pos)) { kn++; continue; }      // (a lane without a start, or one whose start lies behind us already)
+                const uint32_t stop = kn < nl ? s_g[kn] : SPX_NONE;
+                atomicAdd(&flags[2], 1u);                                    // (how often: a developer's number, LZ4F_MI355X_PROF prints it)
+                SpxCur c{nx.pos, nx.seq, nx.out, 0, 0};
+                spx_begin(in, readable, c);
+                for (;;) {
+                    if (c.pos >= stop) break;
+                    if (++rescue > SPX_RESCUE) { bad = true; break; }
+                    const int r = spx_step(in, csize, readable, c);
+                    if (r == 1) { ended = 1; break; }
+                    if (r == 2) { bad = true; break; }
+                }
+                if (bad) break;
+                nx = SpxPoint{c.pos, c.seq, c.out};
             }
             if (bad) break;
-            nx = SpxPoint{c.pos, c.seq, c.out};
+            if (ended) {
+                if (nx.pos != csize) { bad = true; break; }
+                total_seq = nx.seq; total_out = nx.out; break;
+            }
+            k = kn; cur = nx;
         }
-        if (bad) break;
-        if (ended) {
-            if (nx.pos != csize) { bad = true; break; }
-            total_seq = nx.seq; total_out = nx.out; break;
-        }
-        k = kn; cur = nx;
-    }
 #ifdef SPX_PROF
-    { const unsigned long long z5 = clock64(); atomicMax(&flags[42], (uint32_t)(z5 - z4)); atomicMax(&flags[43], (uint32_t)(z5 - z0)); atomicAdd(&flags[46], (uint32_t)((z5 - z4) >> 8)); }
+        { const unsigned long long z5 = clock64(); atomicMax(&flags[42], (uint32_t)(z5 - z4)); atomicMax(&flags[43], (uint32_t)(z5 - z0)); atomicAdd(&flags[46], (uint32_t)((z5 - z4) >> 8)); }
 #endif
-    if (bad || total_seq == 0) { atomicOr(flags, 1u); cnt[b] = 0; osz[b] = 0; nr[b] = 0; return; }
-    Tb[stretches] = SpxPoint{csize, total_seq, total_out};                   // the end, as the last stretch's stop
-    cnt[b] = total_seq; osz[b] = total_out; nr[b] = stretches;
+        if (bad || total_seq == 0) { atomicOr(flags, 1u); cnt[b] = 0; osz[b] = 0; nr[b] = 0; s_fail = 1; }
+        else {
+            Tb[tpos] = SpxPoint{csize, total_seq, total_out};                // the end, as the last run's stop
+            cnt[b] = total_seq; osz[b] = total_out; nr[b] = tpos;
+        }
+    }
+    __syncthreads();
+    // ---- every true lane writes its points: its start, and what it noted on the way, in true counts ----
+    if (s_fail || u >= nl || s_tidx[u] == SPX_NONE) return;
+    {
+        const uint32_t at = s_tidx[u], bs = s_bseq[u], bo = s_bout[u], ns = s_nsub[u];
+        Tb[at] = SpxPoint{s_g[u], bs, bo};
+        for (uint32_t i = 0; i < ns; i++) { const SpxPoint q = s_sub[u][i]; Tb[at + 1 + i] = SpxPoint{q.pos, bs + q.seq, bo + q.out}; }
+    }
 }
 
 // ---- k_spx_parse: a lane per stretch ----
@@ -304,7 +332,7 @@ __global__ __launch_bounds__(128) void k_spx_parse(const uint8_t* __restrict__ f
     const BlockOut e = table[b];
     const uint32_t csize = e.word & 0x7FFFFFFFu;
     if (stretches && ((e.word >> 31) || e.src_off + csize > frame_cap || (uint64_t)blk.seq_base + blk.nseq > desc_cap)) { if (threadIdx.x == 0) atomicOr(flags, 1u); return; }
-    const SpxPoint* Tb = T + (size_t)b * (SPX_MAXSEG + 1);
+    const SpxPoint* Tb = T + (size_t)b * (SPX_MAXPT + 1);
     for (uint32_t k = threadIdx.x; k < stretches; k += blockDim.x) {
         const SpxPoint from = Tb[k], to = Tb[k + 1];
         const bool is_tail = k + 1 == stretches;
@@ -336,8 +364,8 @@ struct FzSrcSpx {
     __device__ __forceinline__ bool make(uint32_t b, const IxBlock& blk, uint32_t csize, uint32_t, FzRunsSpx& r) const
     {
         const uint32_t stretches = nr[b];
-        if (stretches == 0 || stretches > SPX_MAXSEG) return false;
-        r = FzRunsSpx{T + (size_t)b * (SPX_MAXSEG + 1), stretches, blk.nseq, csize};
+        if (stretches == 0 || stretches > SPX_MAXPT) return false;
+        r = FzRunsSpx{T + (size_t)b * (SPX_MAXPT + 1), stretches, blk.nseq, csize};
         return true;
     }
 };

@@ -562,10 +562,10 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             const uint32_t cpb = j.block_size / pick_chunk_size(j.block_size);
             const size_t fixed = ix_entries_at(n_max, cpb);
             if (selfcnt.ensure((size_t)n_max * 8 + 64) || seqcnt.ensure(256 + (size_t)n_max * (8 + 8 * IXL_PUB)) || selfix.ensure(fixed + 64) || density.ensure(64) ||
-                spx.ensure((size_t)n_max * ((SPX_MAXSEG + 1) * sizeof(SpxPoint) + 4) + 64))
+                spx.ensure((size_t)n_max * ((SPX_MAXPT + 1) * sizeof(SpxPoint) + 4) + 64))
                 return make_err(LZ4F_ERROR_allocation_failed);
             uint32_t* cnt = (uint32_t*)selfcnt.p; uint32_t* osz = cnt + n_max;
-            SpxPoint* spt = (SpxPoint*)spx.p; uint32_t* snr = (uint32_t*)((uint8_t*)spx.p + (size_t)n_max * (SPX_MAXSEG + 1) * sizeof(SpxPoint));
+            SpxPoint* spt = (SpxPoint*)spx.p; uint32_t* snr = (uint32_t*)((uint8_t*)spx.p + (size_t)n_max * (SPX_MAXPT + 1) * sizeof(SpxPoint));
             HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 256, st));
             hipLaunchKernelGGL(k_density_probe, dim3(1), dim3(64), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, (uint32_t*)density.p);
             hipLaunchKernelGGL(k_spx_index, dim3(n_max), dim3(128), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, cnt, osz,
@@ -640,7 +640,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                     tick(8, true);
                     tick(9, false);
                     if (spx_mode) {
-                        const FzSrcSpx src{(const SpxPoint*)spx.p, (const uint32_t*)((const uint8_t*)spx.p + (size_t)n_max * (SPX_MAXSEG + 1) * sizeof(SpxPoint))};
+                        const FzSrcSpx src{(const SpxPoint*)spx.p, (const uint32_t*)((const uint8_t*)spx.p + (size_t)n_max * (SPX_MAXPT + 1) * sizeof(SpxPoint))};
                         if (j.block_size <= (1u << 20))
                             hipLaunchKernelGGL((k_copy_selffed<FzCfgS4, FzSrcSpx>), dim3(n_ix), dim3(64 * 4), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, tbl, (const ResultRec*)d_res, n_ix,
                                                (const void*)d_index, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, iprof, src);
@@ -663,7 +663,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 } else {
                 if (spx_mode)                                                                 // (no entries: the stretches between the blocks' check lines)
                     hipLaunchKernelGGL(k_spx_parse, dim3(n_ix), dim3(128), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl, (const ResultRec*)d_res, n_ix,
-                                       (const void*)d_index, (const SpxPoint*)spx.p, (const uint32_t*)((const uint8_t*)spx.p + (size_t)n_max * (SPX_MAXSEG + 1) * sizeof(SpxPoint)),
+                                       (const void*)d_index, (const SpxPoint*)spx.p, (const uint32_t*)((const uint8_t*)spx.p + (size_t)n_max * (SPX_MAXPT + 1) * sizeof(SpxPoint)),
                                        (SeqDesc*)desc.p, (uint32_t*)seqcnt.p);
                 else
                 hipLaunchKernelGGL(k_parse_indexed, dim3((n_lanes + 255) / 256), dim3(256), 0, st, j.d_frame, (uint64_t)j.frame_cap,
