@@ -1119,13 +1119,10 @@ struct FzRunsIx {
 
 template <class C, class RUNS>
 __device__ __forceinline__ void fz_feeder_parse(FzShared<C>& sh, const RUNS& runs, const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable,
-                                                SeqDesc* desc, uint32_t nseq, uint32_t cap, unsigned long long* prof)
+                                                SeqDesc* desc, uint32_t nseq, uint32_t cap, unsigned long long* prof, uint32_t round_max)
 {
-#ifdef FZ_TEST_ROUND      // development: a round so small that every stretch of a foreign frame goes in pieces (the `part` path below)
-    constexpr uint32_t OPR = FzOpr<C>::N, OMASK = OPR - 1, ROUND_MAX = FZ_TEST_ROUND;
-#else
-    constexpr uint32_t OPR = FzOpr<C>::N, OMASK = OPR - 1, ROUND_MAX = OPR / 2;
-#endif
+    constexpr uint32_t OPR = FzOpr<C>::N, OMASK = OPR - 1;
+    const uint32_t ROUND_MAX = (round_max >= 17u && round_max < OPR / 2) ? round_max : OPR / 2;      // (a test switch, LZ4F_MI355X_FEED_ROUND: rounds so small that every stretch of a foreign frame goes in pieces - the `part` path below)
     unsigned long long t_parse = 0, t_res = 0, t_ring = 0, n_round = 0, t_load = 0;
     const unsigned long long t_begin = clock64();
     uint32_t* opr = (uint32_t*)&sh.stage[0][0];
@@ -1292,7 +1289,7 @@ __device__ __forceinline__ void fz_feeder_parse(FzShared<C>& sh, const RUNS& run
 // the workgroup of fz_decode_block<C, true>, its first wave feeding itself
 template <class C, class RUNS>
 __device__ __forceinline__ int32_t fz_decode_block_self(FzShared<C>& sh, const RUNS& runs, const uint8_t* __restrict__ in, uint32_t csize, uint64_t readable,
-                                                        uint8_t* out, uint32_t cap, const uint8_t* safe, unsigned long long* prof, SeqDesc* desc, uint32_t nseq)
+                                                        uint8_t* out, uint32_t cap, const uint8_t* safe, unsigned long long* prof, SeqDesc* desc, uint32_t nseq, uint32_t round_max)
 {
     const uint32_t wave = uni(threadIdx.x >> 6);
     __syncthreads();
@@ -1301,7 +1298,7 @@ __device__ __forceinline__ int32_t fz_decode_block_self(FzShared<C>& sh, const R
     __syncthreads();
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);
-        fz_feeder_parse<C, RUNS>(sh, runs, in, csize, readable, desc, nseq, cap, prof);
+        fz_feeder_parse<C, RUNS>(sh, runs, in, csize, readable, desc, nseq, cap, prof, round_max);
         __builtin_amdgcn_s_setprio(0);
     }
     else fz_copier<C, true>(sh, in, out, wave - 1, safe, prof, nullptr);
@@ -1326,7 +1323,7 @@ struct FzSrcIx {
 template <class C, class RSRC>
 __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_selffed(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint8_t* dst, BlockOut* __restrict__ table,
                                                                    const ResultRec* __restrict__ res, uint32_t n_max, const void* __restrict__ ix,
-                                                                   SeqDesc* desc, uint32_t* __restrict__ flags, unsigned long long* prof, RSRC rsrc)
+                                                                   SeqDesc* desc, uint32_t* __restrict__ flags, unsigned long long* prof, RSRC rsrc, uint32_t round_max)
 {
     __shared__ FzShared<C> sh;
     if (res->status != ST_OK || *flags || flags[IXT_FLAG]) return;           // index unusable (k_check_index): the generic kernel launched behind does the work
@@ -1361,7 +1358,7 @@ __global__ __launch_bounds__(64 * C::WAVES, FZ_FED_OCC) void k_copy_selffed(cons
         } else {
             typename RSRC::Runs runs;
             if (rsrc.make(b, blk, csz, flags[8], runs))
-                got = fz_decode_block_self<C>(sh, runs, frame + e.src_off, csz, frame_cap - e.src_off, dst + e.dst_off, e.dst_size, frame, prof, desc + blk.seq_base, blk.nseq);
+                got = fz_decode_block_self<C>(sh, runs, frame + e.src_off, csz, frame_cap - e.src_off, dst + e.dst_off, e.dst_size, frame, prof, desc + blk.seq_base, blk.nseq, round_max);
         }
     }
     if (tid == 0) { if (got < 0) atomicOr(flags, 2u); else table[b].dst_size = (uint32_t)got; }

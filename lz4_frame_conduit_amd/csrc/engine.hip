@@ -86,6 +86,7 @@ void lz4f_mi355x_engine::Switches::read()
     no_trace = on("LZ4F_MI355X_NO_TRACE"); no_doubling = on("LZ4F_MI355X_NO_DOUBLING"); trace_always = on("LZ4F_MI355X_TRACE_ALWAYS");
     no_groups = on("LZ4F_MI355X_NO_GROUPS"); no_window = on("LZ4F_MI355X_NO_WINDOW"); serial_walk = on("LZ4F_MI355X_SERIAL_WALK");
     no_trailer = on("LZ4F_MI355X_NO_TRAILER"); no_density_probe = on("LZ4F_MI355X_NO_DENSITY_PROBE"); no_spx = on("LZ4F_MI355X_NO_SPX"); no_overlap = on("LZ4F_MI355X_NO_OVERLAP"); no_content_check = on("LZ4F_MI355X_NO_CONTENT_CHECK"); prof = on("LZ4F_MI355X_PROF"); e1_sync = on("LZ4F_MI355X_E1_SYNC"); no_selffeed = on("LZ4F_MI355X_NO_SELFFEED");
+    feed_round = 0; if (const char* v = getenv("LZ4F_MI355X_FEED_ROUND")) { const int k = atoi(v); if (k >= 17 && k <= 4096) feed_round = (unsigned)k; }
     chain_gate = 0; if (const char* v = getenv("LZ4F_MI355X_CHAIN_GATE")) { const int g = atoi(v); if (g > 0 && g < (1 << 20)) chain_gate = g; }
     decode_mode = 0; if (const char* v = getenv("LZ4F_MI355X_DECODE")) decode_mode = v[0];
     e1_run = 0; if (const char* v = getenv("LZ4F_MI355X_E1_RUN")) { const int g = atoi(v); if (g >= 1 && g <= 4096) e1_run = (unsigned)g; }
@@ -643,18 +644,18 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                         const FzSrcSpx src{(const SpxPoint*)spx.p, (const uint32_t*)((const uint8_t*)spx.p + (size_t)n_max * (SPX_MAXPT + 1) * sizeof(SpxPoint))};
                         if (j.block_size <= (1u << 20))
                             hipLaunchKernelGGL((k_copy_selffed<FzCfgS4, FzSrcSpx>), dim3(n_ix), dim3(64 * 4), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, tbl, (const ResultRec*)d_res, n_ix,
-                                               (const void*)d_index, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, iprof, src);
+                                               (const void*)d_index, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, iprof, src, sw.feed_round);
                         else
                             hipLaunchKernelGGL((k_copy_selffed<FzCfgS8, FzSrcSpx>), dim3(n_ix), dim3(64 * 8), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, tbl, (const ResultRec*)d_res, n_ix,
-                                               (const void*)d_index, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, iprof, src);
+                                               (const void*)d_index, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, iprof, src, sw.feed_round);
                     } else {
                         const FzSrcIx src{(const void*)d_index, n_ix};
                         if (j.block_size <= (1u << 20))
                             hipLaunchKernelGGL((k_copy_selffed<FzCfgS4, FzSrcIx>), dim3(n_ix), dim3(64 * 4), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, tbl, (const ResultRec*)d_res, n_ix,
-                                               (const void*)d_index, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, iprof, src);
+                                               (const void*)d_index, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, iprof, src, sw.feed_round);
                         else
                             hipLaunchKernelGGL((k_copy_selffed<FzCfgS8, FzSrcIx>), dim3(n_ix), dim3(64 * 8), 0, st, j.d_frame, (uint64_t)j.frame_cap, j.d_dst, tbl, (const ResultRec*)d_res, n_ix,
-                                               (const void*)d_index, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, iprof, src);
+                                               (const void*)d_index, (SeqDesc*)desc.p, (uint32_t*)seqcnt.p, iprof, src, sw.feed_round);
                     }
                     tick(9, true);
                     indexed = true;

@@ -1181,7 +1181,8 @@ def test_foreign_big_independent_blocks_stretch_parallel(L):
         for kw in (dict(bsid=7, indep=1), dict(bsid=6, indep=1, bck=1), dict(bsid=5, indep=1, cck=1)):
             frames.append((name, kw, data, oracle.conduit_compress(data.tobytes(), oracle.mkprefs(**kw))))
     import os
-    for env in ({}, {"LZ4F_MI355X_NO_SELFFEED": "1"}, {"LZ4F_MI355X_NO_SPX": "1"}):
+    # (LZ4F_MI355X_FEED_ROUND=24: the copy kernel's first wave parses rounds of 24 sequences, so that every run of a foreign frame goes in pieces)
+    for env in ({}, {"LZ4F_MI355X_FEED_ROUND": "24"}, {"LZ4F_MI355X_NO_SELFFEED": "1"}, {"LZ4F_MI355X_NO_SPX": "1"}):
         os.environ.update(env)
         L.lz4f_mi355x_release_engines()
         try:
