@@ -34,7 +34,10 @@
 
 namespace lz4f {
 
-constexpr uint32_t SPX_SEG = 32768, SPX_SCAN = 8192, SPX_CAND = 6, SPX_MAXSEG = (4u << 20) / SPX_SEG;      // lanes per block <= 128
+#ifndef SPX_SEG_BYTES
+#define SPX_SEG_BYTES 32768
+#endif
+constexpr uint32_t SPX_SEG = SPX_SEG_BYTES, SPX_SCAN = 8192, SPX_CAND = 6, SPX_MAXSEG = (4u << 20) / SPX_SEG;      // lanes per block <= 128
 constexpr uint32_t SPX_LANE_HOPS = 2048;                        // sequences a lane follows before it gives its stretch up (sparse payloads: >= 24 bytes per sequence, 1400 per stretch)
 constexpr uint32_t SPX_RESCUE = 1u << 16;                       // sequences the stitching thread may walk itself per block before it gives up
 constexpr uint32_t SPX_NONE = 0xFFFFFFFFu;
@@ -105,7 +108,7 @@ __device__ __forceinline__ bool spx_likely_token(const uint8_t* __restrict__ in,
 
 // ---- k_spx_index: a workgroup per block ----
 // T (SPX_MAXPT + 1 points per block): T[k] = where run k starts (k = 0: byte 0) - a stretch's start, or what its lane noted on the way -, T[runs] = the payload's end; nr[b]: runs.
-__global__ __launch_bounds__(128) void k_spx_index(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
+__global__ __launch_bounds__(SPX_MAXSEG) void k_spx_index(const uint8_t* __restrict__ frame, uint64_t frame_cap, const BlockOut* __restrict__ table,
                                                    const ResultRec* __restrict__ res, uint32_t n_max, uint32_t* __restrict__ cnt, uint32_t* __restrict__ osz,
                                                    SpxPoint* __restrict__ T, uint32_t* __restrict__ nr, uint32_t* __restrict__ flags,
                                                    const uint32_t* __restrict__ only_if)

@@ -569,7 +569,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             SpxPoint* spt = (SpxPoint*)spx.p; uint32_t* snr = (uint32_t*)((uint8_t*)spx.p + (size_t)n_max * (SPX_MAXPT + 1) * sizeof(SpxPoint));
             HIP_TRY(hipMemsetAsync(seqcnt.p, 0, 256, st));
             hipLaunchKernelGGL(k_density_probe, dim3(1), dim3(64), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, (uint32_t*)density.p);
-            hipLaunchKernelGGL(k_spx_index, dim3(n_max), dim3(128), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, cnt, osz,
+            hipLaunchKernelGGL(k_spx_index, dim3(n_max), dim3(SPX_MAXSEG), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, cnt, osz,
                                spt, snr, (uint32_t*)seqcnt.p, sw.no_density_probe ? (const uint32_t*)nullptr : (const uint32_t*)density.p + 1);
             uint32_t tot[10];
             for (int pass = 0; pass < 2; pass++) {
