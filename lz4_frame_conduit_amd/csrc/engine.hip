@@ -508,7 +508,11 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
         // index unusable when the stream had more sequences than it had room for, and then one is made here instead.
         IxHeader hd_now; memset(&hd_now, 0, sizeof(hd_now));
         bool have_now = false;
-        if (mode == 'f' && j.linked && j.d_index && j.index_size >= sizeof(IxHeader) && !sw.no_index) {
+        // (an index out of the frame's trailer brings its counts in the footer - no read - and its frame is one call's work: every block but the last is full,
+        // so the table the list check writes has every block's place in the output, which is what a linked frame's indexed decode needs; if a trailer lies about
+        // that the descriptors do not tile the blocks and the generic kernels take the frame)
+        const bool ix_by_trailer = j.d_index && j.ix_seqs && j.hint_list && j.hint_n <= n_max;
+        if (mode == 'f' && j.linked && j.d_index && j.index_size >= sizeof(IxHeader) && !sw.no_index && !ix_by_trailer) {
             HIP_TRY(hipMemcpyAsync(&hd_now, j.d_index, sizeof(hd_now), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             have_now = true;
@@ -596,7 +600,7 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             }
         }
         // (linked frames: only with a table that has every block's output position - the compressor's, or the one just made)
-        if (mode == 'f' && d_index && index_size >= sizeof(IxHeader) && (!j.linked || self_indexed || ((j.d_table || j.table_in_place || j.table_direct) && j.hist0 <= 65536)) &&
+        if (mode == 'f' && d_index && index_size >= sizeof(IxHeader) && (!j.linked || self_indexed || ((j.d_table || j.table_in_place || j.table_direct || ix_by_trailer) && j.hist0 <= 65536)) &&
             !sw.no_index) {
             // Descriptors from the compressor's sequence index: a lane per entry parses, a lane per sequence resolves direct
             // matches, a workgroup per block copies.
@@ -1352,7 +1356,7 @@ size_t lz4f_mi355x_dev_decompressFrame(lz4f_mi355x_engine* e, void* d_dst, size_
             if (ix_at + sizeof(foot) <= frameCapacity) {
                 j.hint_list = (const uint64_t*)((const uint8_t*)d_frame + list_at); j.hint_n = foot.n_blocks;      // (frame_cap stays the whole buffer: `at` is a claim)
                 const uint64_t ix_bytes = frameCapacity - sizeof(foot) - ix_at;
-                if (ix_bytes >= sizeof(IxHeader) && !j.linked && foot.total_seqs) { j.d_index = (void*)((const uint8_t*)d_frame + ix_at); j.index_size = (size_t)ix_bytes; j.ix_seqs = foot.total_seqs; j.ix_entries = foot.total_entries; }
+                if (ix_bytes >= sizeof(IxHeader) && foot.total_seqs) { j.d_index = (void*)((const uint8_t*)d_frame + ix_at); j.index_size = (size_t)ix_bytes; j.ix_seqs = foot.total_seqs; j.ix_entries = foot.total_entries; }
             }
         }
     }

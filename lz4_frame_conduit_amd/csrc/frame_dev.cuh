@@ -724,7 +724,7 @@ __global__ void k_trailer_plan(uint8_t* __restrict__ dst, uint64_t dst_cap, Resu
     if (res->status == ST_OK && n_blocks) {
         const uint64_t F = res->size;
         const IxHeader* hd = (const IxHeader*)ix;
-        const bool with_ix = ix && hd->magic == IX_MAGIC && hd->pad0 == 0;      // (pad0: linked frames; their decoder indexes them itself)
+        const bool with_ix = ix && hd->magic == IX_MAGIC;                        // (round 4: linked frames too - until then their decoder indexed them itself, 0.3 ms per GiB of 64 KiB blocks)
         p.at = F;
         p.list_at = (F + 8 + 15) & ~(uint64_t)15;
         p.n_list = (n_blocks + 1) & ~1u;
