@@ -897,7 +897,8 @@ def test_inband_trailer_interop_and_robustness(L):
         r2 = eng.result()
         assert r2.size == src.numel() and r2.consumed == used and torch.equal(back, src), name
         path = int(r2.flags) >> 12                                                       # the trailer's list and its index were used - for a linked frame too (round 4:
-        assert path & PATH["trailer"] and path & PATH["indexed"] and not path & PATH["dropped"], (name, hex(path))      # until then its decoder indexed it itself)
+        assert path & PATH["trailer"] and not path & PATH["dropped"], (name, hex(path))      # until then its decoder indexed it itself)
+        if name != "text": assert path & PATH["indexed"], (name, hex(path))              # (a dense stream overflows the index it is given: its trailer is the block list alone)
         if name == "linked": assert not path & PATH["self_index"], hex(path)
         # damage: bytes of the block list, of the index, of the footer; a footer that names another block count; a cut trailer
         tr = len(stream) - used
