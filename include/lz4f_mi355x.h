@@ -229,8 +229,10 @@ LZ4F_MI355X_API void*  lz4f_mi355x_engine_stream(lz4f_mi355x_engine* e);
  * which wave got there first.  Every frame is a valid LZ4 frame that decodes to the input, and the size varies by ~1e-5 between
  * runs (4 GiB of the bench input: 2 189 936 735 .. 2 189 966 976 bytes) - but two compressions of the same input are in general
  * NOT byte-identical.  Where that matters (reproducible archives, deduplication, content-addressed stores) switch the engine to
- * the deterministic parse: one wave per workgroup takes the slices in order (the others only move data), equal input then gives
- * equal bytes, at about a tenth of the match finder's speed (measured: DESIGN.md section 4).  Engines of the host-pointer calls
+ * the deterministic search (round 4: csrc/encode_solo.cuh): one wave per 64 KiB chunk with a hash table of its own - nothing shared
+ * between waves, so the records are a function of the input alone; equal input then gives equal bytes, on the bench input at 1.8x
+ * the default match finder's time and 0.7 % of its ratio (text: 6x, 2 %; until round 4: one wave per workgroup of the shared search
+ * parsing in order, 10x), with the worst-case record workspace, 2 bytes per input byte.  Engines of the host-pointer calls
  * and of the LZ4F_* streaming functions read LZ4F_MI355X_DETERMINISTIC=1 from the environment when they are made.
  * Decoding is deterministic always. */
 LZ4F_MI355X_API size_t lz4f_mi355x_engine_set_deterministic(lz4f_mi355x_engine* e, int enable);

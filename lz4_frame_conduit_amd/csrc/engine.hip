@@ -304,6 +304,11 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
             // workspace is new, or when a call before this one may not have got as far as its scan)
             if (recs_ctl_clean != recs.p) { HIP_TRY(hipMemsetAsync(recs.p, 0, 64, st)); }
             recs_ctl_clean = nullptr;
+            // deterministic mode: a wave per chunk with a table of its own (encode_solo.cuh) - nothing shared, nothing that depends on timing.
+            // (e1_solo bit 2: the shared kernel with one wave per workgroup parsing, the mode's form until round 4 - kept for comparison)
+            if ((sw.e1_solo & 1u) && !(sw.e1_solo & 4u))
+                hipLaunchKernelGGL((k_find_matches_solo<1>), dim3(g.n_chunks), dim3(64), 0, st, j.d_src, g, (ChunkInfo*)info.p, (uint64_t*)recs.p);
+            else
             hipLaunchKernelGGL(k_find_matches, dim3(n_wg), dim3(64 * E1_WAVES), 0, st, j.d_src, g, (ChunkInfo*)info.p, (uint64_t*)recs.p, (uint64_t*)e1_scratch.p);
             if (sw.e1_sync) (void)hipStreamSynchronize(st);
 #ifdef E1_DEBUG

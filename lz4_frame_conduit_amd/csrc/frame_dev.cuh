@@ -10,6 +10,7 @@
 #include "decode_fused.cuh"
 #include "decode_linked.cuh"
 #include "encode.cuh"
+#include "encode_solo.cuh"
 #include "decode_indexed.cuh"
 #include "decode_spx.cuh"
 
