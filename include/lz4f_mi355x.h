@@ -230,8 +230,8 @@ LZ4F_MI355X_API void*  lz4f_mi355x_engine_stream(lz4f_mi355x_engine* e);
  * runs (4 GiB of the bench input: 2 189 936 735 .. 2 189 966 976 bytes) - but two compressions of the same input are in general
  * NOT byte-identical.  Where that matters (reproducible archives, deduplication, content-addressed stores) switch the engine to
  * the deterministic search (round 4: csrc/encode_solo.cuh): one wave per 64 KiB chunk with a hash table of its own - nothing shared
- * between waves, so the records are a function of the input alone; equal input then gives equal bytes, on the bench input at 1.8x
- * the default match finder's time and 0.7 % of its ratio (text: 6x, 2 %; until round 4: one wave per workgroup of the shared search
+ * between waves, so the records are a function of the input alone; equal input then gives equal bytes, on the bench input at 1.4x
+ * the default match finder's time and the same ratio (text: 6x the time, 2 % of the ratio; until round 4: one wave per workgroup of the shared search
  * parsing in order, 10x), with the worst-case record workspace, 2 bytes per input byte.  Engines of the host-pointer calls
  * and of the LZ4F_* streaming functions read LZ4F_MI355X_DETERMINISTIC=1 from the environment when they are made.
  * Decoding is deterministic always. */

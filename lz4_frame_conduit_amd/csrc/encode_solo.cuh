@@ -18,6 +18,10 @@ namespace lz4f {
 constexpr uint32_t SOLO_HASH_LOG = 12, SOLO_HASH_SIZE = (15u << SOLO_HASH_LOG) >> 4;      // 15/16 of 4096 entries: what fits 14 waves into a CU
 constexpr uint32_t SOLO_TAG_BITS = 8, SOLO_TAG_MASK = 0xFFu;
 constexpr uint32_t SOLO_SEED_STRIDE = 4, SOLO_SEED_DENSE = 1024;
+#ifndef SOLO_STEP_LONG
+#define SOLO_STEP_LONG 4
+#endif
+constexpr uint32_t SOLO_LONG_MATCH = 192;
 __device__ __forceinline__ uint32_t solo_slot(uint32_t hv) { return ((hv >> (32 - SOLO_HASH_LOG)) * 15u) >> 4; }
 
 // grid: one wave per chunk (blockDim = 64 * WAVES_PER_WG)
@@ -251,7 +255,10 @@ __global__ __launch_bounds__(64 * WAVES_PER_WG) void k_find_matches_solo(const u
             body += seq_size(lit, mlen);
             nrec++;
             anchor = ip = mp + mlen;
-            step = 1;
+            // (behind a long match the search goes on at stride SOLO_STEP_LONG, as the shared search does where sequences are long: what follows a 512-byte copy of
+            // the bench input is 512 random bytes - strides 1..6 took three rounds of two steps to get across them, 4 and 5 take one; a match found a few bytes late gets
+            // its start back from the backward extension)
+            step = (SOLO_STEP_LONG > 1 && mlen >= SOLO_LONG_MATCH) ? (uint32_t)SOLO_STEP_LONG : 1u;
             if (nrec >= g.max_rec_per_chunk) break;          // cannot happen with chunk/4+1 slots; belt and braces
             // like the CPU encoder, also index ip-2; its bytes are requested together with the refilled stream queue
             const bool ins2 = ip >= 2 + cs && ip + 2 <= ce;
