@@ -1142,6 +1142,19 @@ def test_deterministic_encoder_mode(L):
         assert len(seen) == 1
     finally:
         os.environ.pop("LZ4F_MI355X_RECS_PER_TILE", None)
+    # the twelve LZ4F_* functions (the reference's call pattern, Conduit.hsc:457-533): their engines read LZ4F_MI355X_DETERMINISTIC when they are made
+    os.environ["LZ4F_MI355X_DETERMINISTIC"] = "1"
+    L.lz4f_mi355x_release_engines()
+    try:
+        data = inputs["synth50"][:3 << 20].tobytes() + inputs["text"][:1 << 20].tobytes()
+        chunks = [data[i:i + 16384] for i in range(0, len(data), 16384)]
+        a = b"".join(conduit.compress(chunks)); b = b"".join(conduit.compress(chunks))
+        assert a == b
+        out, used = oracle.decompress_frame(a, cap=len(data) + 64)
+        assert used == len(a) and out == data
+    finally:
+        os.environ.pop("LZ4F_MI355X_DETERMINISTIC", None)
+        L.lz4f_mi355x_release_engines()
 
 
 def _short_sequences(n: int, seed: int) -> np.ndarray:
