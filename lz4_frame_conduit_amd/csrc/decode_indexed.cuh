@@ -634,8 +634,9 @@ static_assert(IXT_REGION == IXT_WG_BYTES, "one workgroup per region");
 __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ frame, uint64_t frame_cap, uint8_t* dst, const BlockOut* __restrict__ table,
                                                     const ResultRec* __restrict__ res, uint32_t n_max, void* __restrict__ ix, const SeqDesc* __restrict__ desc,
                                                     const uint32_t* __restrict__ dsrc, const uint32_t* __restrict__ postab, uint32_t* flags,
-                                                    uint32_t linked, uint32_t block_size, uint64_t hist0, uint32_t* region_cnt, uint32_t count_it)
-{
+                                                    uint32_t linked, uint32_t block_size, uint64_t hist0, uint32_t* region_cnt, uint32_t count_it, uint32_t n_wg)
+{   // n_wg: 4 KiB pieces of output, a workgroup's work each; the grid strides over them (the kernel is launched for every linked frame and returns at once
+    // unless the frame is dense: as a grid of a workgroup per piece that was 57 us of empty dispatches per GiB, a tenth of a sparse frame's decode)
     __shared__ uint32_t go;
     __shared__ uint64_t stk_g[IXT_STACK][256];                          // per thread: the ranges set aside where a trace split (see below)
     __shared__ uint32_t stk_s[IXT_STACK][256];
@@ -643,12 +644,13 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ 
     __syncthreads();
     if (!go) return;
     const uint32_t n = res->n_blocks < n_max ? res->n_blocks : n_max;
+    for (uint32_t wgi = blockIdx.x; wgi < n_wg; wgi += gridDim.x) {
     // which 4 KiB of the output is this workgroup's
     uint64_t wg_pos;
-    if (linked || block_size <= IXT_REGION) wg_pos = (uint64_t)blockIdx.x * IXT_WG_BYTES;
+    if (linked || block_size <= IXT_REGION) wg_pos = (uint64_t)wgi * IXT_WG_BYTES;
     else {
         const uint32_t per_k = n_max * (IXT_REGION / IXT_WG_BYTES);
-        const uint32_t k = blockIdx.x / per_k, rem = blockIdx.x % per_k;
+        const uint32_t k = wgi / per_k, rem = wgi % per_k;
         wg_pos = (uint64_t)(rem / (IXT_REGION / IXT_WG_BYTES)) * block_size + (uint64_t)k * IXT_REGION + (uint64_t)(rem % (IXT_REGION / IXT_WG_BYTES)) * IXT_WG_BYTES;
     }
     const bool have_dsrc = flags[IXT_FLAG] != 2u;                      // (2: k_resolve_direct was skipped)
@@ -775,6 +777,8 @@ __global__ __launch_bounds__(256) void k_trace_copy(const uint8_t* __restrict__ 
     if (threadIdx.x == 0 && wg_bytes) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         __hip_atomic_fetch_add(region_cnt + my_region, wg_bytes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
     }
 }
 
