@@ -86,6 +86,7 @@ void lz4f_mi355x_engine::Switches::read()
     no_trace = on("LZ4F_MI355X_NO_TRACE"); no_doubling = on("LZ4F_MI355X_NO_DOUBLING"); trace_always = on("LZ4F_MI355X_TRACE_ALWAYS");
     no_groups = on("LZ4F_MI355X_NO_GROUPS"); no_window = on("LZ4F_MI355X_NO_WINDOW"); serial_walk = on("LZ4F_MI355X_SERIAL_WALK");
     no_trailer = on("LZ4F_MI355X_NO_TRAILER"); no_density_probe = on("LZ4F_MI355X_NO_DENSITY_PROBE"); no_spx = on("LZ4F_MI355X_NO_SPX"); no_overlap = on("LZ4F_MI355X_NO_OVERLAP"); no_content_check = on("LZ4F_MI355X_NO_CONTENT_CHECK"); prof = on("LZ4F_MI355X_PROF"); e1_sync = on("LZ4F_MI355X_E1_SYNC"); no_selffeed = on("LZ4F_MI355X_NO_SELFFEED");
+    group_kib = 0; if (const char* v = getenv("LZ4F_MI355X_GROUP_KIB")) { const int k = atoi(v); if (k >= 64 && k <= 4096 && (k & (k - 1)) == 0) group_kib = (unsigned)k; }
     feed_round = 0; if (const char* v = getenv("LZ4F_MI355X_FEED_ROUND")) { const int k = atoi(v); if (k >= 17 && k <= 4096) feed_round = (unsigned)k; }
     chain_gate = 0; if (const char* v = getenv("LZ4F_MI355X_CHAIN_GATE")) { const int g = atoi(v); if (g > 0 && g < (1 << 20)) chain_gate = g; }
     decode_mode = 0; if (const char* v = getenv("LZ4F_MI355X_DECODE")) decode_mode = v[0];
@@ -737,7 +738,10 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 tick(8, true);
                 tick(9, false);
                 // (linked frames of small blocks: a workgroup takes a group of consecutive blocks - see k_copy_indexed)
-                const uint32_t group = (j.linked && j.block_size < (1u << 20) && !sw.no_groups) ? (1u << 20) / j.block_size : 1u;
+                // (a group is 1 MiB of blocks where that fills the machine - 1024 workgroups of the 4-wave shape are half of its wave slots - and less for
+                // smaller frames: LZ4F_MI355X_GROUP_KIB sets it)
+                const uint32_t group_bytes = sw.group_kib ? sw.group_kib << 10 : ((uint64_t)n_ix * j.block_size <= (2ull << 30) ? (512u << 10) : (1u << 20));      // (1 GiB: 512 KiB 0.509 ms, 1 MiB 0.541, 256 KiB 0.788, 2 MiB 0.778)
+                const uint32_t group = (j.linked && j.block_size < group_bytes && !sw.no_groups) ? group_bytes / j.block_size : 1u;
                 const uint32_t n_wg = (n_ix + group - 1) / group;
                 // (how long a group of a linked frame waits for the one in front: half a second plus 20 ticks of the 100 MHz clock per
                 // output byte - 5 MB/s, a fifth of the slowest chain measured (text, linked, 27 MB/s); LZ4F_MI355X_WAIT_TICKS overrides)
