@@ -231,6 +231,14 @@ extern "C" __attribute__((visibility("default"))) int lz4f_mi355x_debug_prof(uns
 // bytes - the densest input of the tests, Zipf text, needs more than 8192 per tile; the bench input one per 2000), never less than 64 tiles' worst case
 // (small calls are sized for the worst case outright) and never more than the worst case.  LZ4F_MI355X_RECS_PER_TILE=16385 is the worst
 // case for every tile; a caller that knows its data is sparse sets it low (1024: 0.13 bytes of workspace per input byte).
+static uint32_t device_cus(int device)
+{
+    static int cus[64];                                                  // (0: not asked yet; a benign race: every thread stores the same number)
+    const unsigned d = (unsigned)device % 64;
+    if (!cus[d]) { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || v < 1) v = 256; cus[d] = v; }
+    return (uint32_t)cus[d];
+}
+
 static uint64_t rec_pool_records(uint32_t n_chunks, uint32_t max_rec_per_chunk, unsigned per_tile)
 {
     const uint64_t worst = (uint64_t)(n_chunks + 1) * max_rec_per_chunk;
@@ -290,9 +298,13 @@ size_t lz4f_mi355x_engine::launch_compress(const CompressJob& j, uint8_t* d_dst,
         tick(0, false);
         {
             // a workgroup (one per CU: ~150 KiB of LDS) takes a run of consecutive 64 KiB tiles.  At most 1024 workgroups (each
-            // has its slice lists in `e1_scratch`), runs of at least 16 tiles where the input is big enough for 1024 of those
-            // (the history loaded in front of a run is then 1/16 of the input or less)
-            uint32_t run = (g.n_chunks + 1023) / 1024; if (run < 16) { run = g.n_chunks / 1024; run = run < 1 ? 1 : run > 16 ? 16 : run; }
+            // has its slice lists in `e1_scratch`).  Round 4: as many workgroups as there are CUs where the input has fewer than 64 tiles
+            // for each, runs of 64 tiles from there on - a run's first tile pays for the 64 KiB of history in front of it, for seeding the
+            // table with them and for not knowing the data's density yet, so fewer, longer runs win until the CUs run out of work:
+            // tools/e1_run_sweep.py, tiles per workgroup 1024-wide rule -> this one: 64 MiB 0.132 -> 0.065 ms (ratio 1.9154 -> 1.9425),
+            // 256 MiB 0.256 -> 0.187, 1 GiB 0.722 -> 0.647, 2 GiB 1.342 -> 1.228; 4 GiB and beyond as before (64 tiles, 1024 workgroups).
+            uint32_t run = g.n_chunks / device_cus(device); run = run < 1 ? 1 : run > 64 ? 64 : run;
+            if ((g.n_chunks + run - 1) / run > 1024) run = (g.n_chunks + 1023) / 1024;
             if (sw.e1_run) run = sw.e1_run;
             g.tiles_per_wg = run;
             g.e1_solo = sw.e1_solo;
