@@ -14,6 +14,8 @@ namespace lz4f {
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;      // (a pointer that keeps its address space: ds_* instructions, not flat_* - which count as memory operations too)
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef uint32_t u32_ua __attribute__((aligned(1)));
 struct __attribute__((packed, aligned(1))) b16_ua { uint32_t a, b, c, d; };   // 16 bytes, any alignment
 struct __attribute__((aligned(4))) w3_a4 { uint32_t a, b, c; };               // 3 dwords, dword aligned

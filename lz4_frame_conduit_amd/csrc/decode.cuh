@@ -135,7 +135,7 @@ __device__ __forceinline__ int32_t wave_decode_block(const uint8_t* __restrict__
 // ds_bpermute; the next window is on its way while this one is parsed).  Same accept/reject rules as wave_decode_block.
 //   readable: bytes that may be read from `in` on (the frame's end), >= csize
 #ifdef DB_PROF      // development: cycle stamps of the lanes' path, summed over the grid's first waves (tools/cfg2_prof.py)
-__device__ unsigned long long g_dbprof[16];
+__device__ unsigned long long g_dbprof[32];
 #define DBP(...) __VA_ARGS__
 #else
 #define DBP(...)
@@ -302,7 +302,7 @@ __device__ __forceinline__ int32_t wave_decode_block_win(const uint8_t* __restri
                 const uint32_t md0 = (uint32_t)__builtin_amdgcn_readlane((int)mdst, 0);          // the window's first match: everything in front of it is stored or on its way
                 const bool indep = is_tok && mdst - off + mlen <= md0;                          // (implies off >= mlen: no overlap with itself either)
                 const uint32_t pa_mine = mdst | (mlen << 24);                             // (a block is at most 4 MiB: 22 bits)
-                volatile uint32_t* const xp = expand;                         // (volatile: see below)
+                volatile lds_u32* const xp = (volatile lds_u32*)expand;        // (volatile: see below; typed as LDS - through a generic pointer these were flat_* operations, each with a wait for every store in flight)
                 uint32_t base = 0;
                 while (base < mtotal) {                                       // rounds of up to 64 match bytes, cut between matches
                     const bool fits = is_tok && mex >= base && mincl <= base + WAVE;

@@ -85,7 +85,7 @@ void lz4f_mi355x_engine::Switches::read()
     no_index = on("LZ4F_MI355X_NO_INDEX"); no_selfindex = on("LZ4F_MI355X_NO_SELFINDEX"); no_resolve = on("LZ4F_MI355X_NO_RESOLVE");
     no_trace = on("LZ4F_MI355X_NO_TRACE"); no_doubling = on("LZ4F_MI355X_NO_DOUBLING"); trace_always = on("LZ4F_MI355X_TRACE_ALWAYS");
     no_groups = on("LZ4F_MI355X_NO_GROUPS"); no_window = on("LZ4F_MI355X_NO_WINDOW"); serial_walk = on("LZ4F_MI355X_SERIAL_WALK");
-    no_trailer = on("LZ4F_MI355X_NO_TRAILER"); no_density_probe = on("LZ4F_MI355X_NO_DENSITY_PROBE"); no_spx = on("LZ4F_MI355X_NO_SPX"); no_overlap = on("LZ4F_MI355X_NO_OVERLAP"); no_content_check = on("LZ4F_MI355X_NO_CONTENT_CHECK"); prof = on("LZ4F_MI355X_PROF"); e1_sync = on("LZ4F_MI355X_E1_SYNC"); no_selffeed = on("LZ4F_MI355X_NO_SELFFEED");
+    no_trailer = on("LZ4F_MI355X_NO_TRAILER"); no_density_probe = on("LZ4F_MI355X_NO_DENSITY_PROBE"); no_spx = on("LZ4F_MI355X_NO_SPX"); no_overlap = on("LZ4F_MI355X_NO_OVERLAP"); no_content_check = on("LZ4F_MI355X_NO_CONTENT_CHECK"); prof = on("LZ4F_MI355X_PROF"); e1_sync = on("LZ4F_MI355X_E1_SYNC"); no_selffeed = on("LZ4F_MI355X_NO_SELFFEED"); dense_mode = 0; if (const char* v = getenv("LZ4F_MI355X_DENSE_MODE")) { const int g = atoi(v); if (g >= 0 && g <= 2) dense_mode = (unsigned)g; }
     group_kib = 0; if (const char* v = getenv("LZ4F_MI355X_GROUP_KIB")) { const int k = atoi(v); if (k >= 64 && k <= 4096 && (k & (k - 1)) == 0) group_kib = (unsigned)k; }
     feed_round = 0; if (const char* v = getenv("LZ4F_MI355X_FEED_ROUND")) { const int k = atoi(v); if (k >= 17 && k <= 4096) feed_round = (unsigned)k; }
     chain_gate = 0; if (const char* v = getenv("LZ4F_MI355X_CHAIN_GATE")) { const int g = atoi(v); if (g > 0 && g < (1 << 20)) chain_gate = g; }
@@ -221,7 +221,7 @@ extern "C" __attribute__((visibility("default"))) int lz4f_mi355x_debug_prof(uns
     (void)hipDeviceSynchronize();
     const int rc = hipMemcpy(out128, g_prof, 1024, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 2;
 #ifdef DB_PROF
-    { unsigned long long z[16] = {0}; (void)hipMemcpyFromSymbol(out128 + 96, HIP_SYMBOL(lz4f::g_dbprof), sizeof(z)); (void)hipMemcpyToSymbol(HIP_SYMBOL(lz4f::g_dbprof), z, sizeof(z)); }
+    { unsigned long long z[32] = {0}; (void)hipMemcpyFromSymbol(out128 + 96, HIP_SYMBOL(lz4f::g_dbprof), sizeof(z)); (void)hipMemcpyToSymbol(HIP_SYMBOL(lz4f::g_dbprof), z, sizeof(z)); }
 #endif
     (void)hipMemset(g_prof, 0, 1024); (void)hipMemset(g_prof + 70, 0xFF, 8); (void)hipMemset(g_prof + 75, 0xFF, 8);      // (the grid-wide words accumulate: start again)
     return rc;
@@ -801,6 +801,13 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
             if (!indexed && !j.linked && !sw.no_density_probe) {
                 if (density.ensure(64)) return make_err(LZ4F_ERROR_allocation_failed);
                 hipLaunchKernelGGL(k_density_probe, dim3(1), dim3(64), 0, st, j.d_frame, (uint64_t)j.frame_cap, (const BlockOut*)tbl, (const ResultRec*)d_res, n_max, (uint32_t*)density.p);
+                // Few big blocks: a wave per block leaves the machine idle and waits out every trip to memory (13-15 GiB/s for a GiB in 4 MiB blocks);
+                // a workgroup per block with the block's window in LDS and its waves taking the payload in turns (decode_relay.cuh) is three times
+                // as fast per block - but it has a CU to itself, so from ~3 blocks per CU on the waves win again (8 GiB in 4 MiB blocks: 90 GiB/s).
+                if (j.block_size > 65536u && sw.dense_mode != 2 && (sw.dense_mode == 1 || n_max <= 3u * device_cus(device)))
+                    hipLaunchKernelGGL((k_decode_blocks_relay<RELAY_W, RELAY_S>), dim3(n_max), dim3(64 * (RELAY_W + RELAY_S + 2)), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_max, (uint64_t)j.frame_cap,
+                                       (const uint32_t*)density.p);
+                else
                 hipLaunchKernelGGL((k_decode_blocks<W>), dim3((n_max + W - 1) / W), dim3(64 * W), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl, (const ResultRec*)d_res,
                                    n_max, 0u, j.block_size, j.hist0, (uint64_t)j.frame_cap, (const uint32_t*)density.p);
                 only_if = (const uint32_t*)density.p + 1;

@@ -69,6 +69,7 @@ struct lz4f_mi355x_engine {
     // live in a pool: lz4f_mi355x_release_engines() makes the next ones read it again)
     struct Switches {
         bool no_index, no_selfindex, no_resolve, no_trace, no_doubling, trace_always, no_groups, no_window, serial_walk, no_trailer, no_content_check, no_density_probe, no_spx, no_overlap, prof, e1_sync, no_selffeed;
+        unsigned dense_mode;           // dense payloads in big independent blocks (LZ4F_MI355X_DENSE_MODE): 0 by block count, 1 workgroup per block (decode_relay.cuh), 2 wave per block
         unsigned group_kib;            // (development) bytes of consecutive small blocks of a linked frame a workgroup of the indexed copy kernel takes
         unsigned feed_round;           // (test switch) sequences per parse round of the self-feeding copy kernel's first wave
         int chain_gate; char decode_mode; unsigned e1_run, e1_solo, seed, dblk_lds, recs_per_tile; unsigned long long wait_ticks;

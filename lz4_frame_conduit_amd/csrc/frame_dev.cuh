@@ -7,6 +7,7 @@
 #pragma once
 #include "common.cuh"
 #include "decode.cuh"
+#include "decode_relay.cuh"
 #include "decode_fused.cuh"
 #include "decode_linked.cuh"
 #include "encode.cuh"

@@ -1256,6 +1256,108 @@ def _lz4_seq(lit: bytes, mlen: int, off: int) -> bytes:
     return bytes(b)
 
 
+def _dense_block(n_out: int, seed: int, specials: bool):
+    """A hand-made LZ4 block of short sequences (dense by the density probe's rule) and what it decodes to: 1..9 literals and a match of 4..18 bytes from
+    anywhere in the last 64 KiB - offsets 1..3 (overlapping), 65535, and with `specials` now and then what the lanes cannot take: literal runs of 15..400 and
+    of 70000 bytes, matches of 19..2000 bytes and of 200000 bytes, a token whose sequence leaves its 64-byte window."""
+    rng = np.random.default_rng(seed)
+    out = bytearray(rng.integers(0, 256, 64, dtype=np.uint8).tobytes())
+    first = bytes(out)
+    seqs = []
+    pending_lit = first
+    while len(out) < n_out - (300000 if specials else 4096):
+        r = int(rng.integers(0, 1000))
+        mlen = int(rng.integers(4, 19))
+        hi = min(len(out), 65535)
+        off = int(rng.integers(1, hi + 1))
+        if r < 30: off = int(rng.integers(1, 4))
+        elif r < 60: off = hi
+        elif r < 200: off = int(rng.integers(1, min(hi, 300) + 1))
+        if specials and r in (500, 501, 502): mlen = int(rng.integers(19, 2000))
+        if specials and r == 503 and len(out) > (1 << 20): mlen = 200000
+        seqs.append((pending_lit, mlen, off))
+        src = len(out) - off
+        for i in range(mlen): out.append(out[src + i])
+        nl = int(rng.integers(1, 10))
+        if specials and r in (600, 601, 602, 603): nl = int(rng.integers(15, 400))
+        if specials and r == 604: nl = 70000
+        if r in (700, 701): nl = 0
+        pending_lit = rng.integers(0, 256, nl, dtype=np.uint8).tobytes()
+        out += pending_lit
+    tail = rng.integers(0, 256, 40, dtype=np.uint8).tobytes()
+    out += tail
+    body = b"".join(_lz4_seq(l, m, o) for l, m, o in seqs) + _lz4_seq(pending_lit + tail, 0, 0)
+    return body, bytes(out)
+
+
+@pytest.mark.gpu
+def test_dense_payloads_in_big_independent_blocks(L):
+    """Text-like payloads in big independent blocks without an index (what `lz4 -c` writes of text, test/Main.hs:33-36): the density probe sends them to the
+    workgroup-per-block decoder whose waves take the payload's 64-byte windows in turn (decode_relay.cuh; LZ4F_MI355X_DENSE_MODE=1: a wave per block with an LDS
+    ring, decode_ring.cuh; 2: a wave per block).  liblz4's bytes of text, and hand-made blocks with every kind of sequence (overlapping matches, offset 65535,
+    long runs and long matches in between, tokens with length bytes), a stored block between them, block and content checksums; truncated room; and single-byte
+    mutations get the oracle's verdicts."""
+    import os, struct, torch
+    from lz4_frame_conduit_amd.device import Engine
+    rng = np.random.default_rng(5)
+    frames = []
+    text = datagen.synth_text(9 << 20, 31)
+    for kw in (dict(bsid=7, indep=1), dict(bsid=6, indep=1, bck=1), dict(bsid=5, indep=1, cck=1)):
+        frames.append(("text", kw, text.tobytes(), oracle.conduit_compress(text.tobytes(), oracle.mkprefs(**kw))))
+    # hand-made: header of an empty frame with the same preferences, then blocks of our own
+    hdr = oracle.conduit_compress(b"", oracle.mkprefs(bsid=7, indep=1))[:7]
+    blocks = [_dense_block(4 << 20, 1, False), _dense_block(3 << 20, 2, True), _dense_block(4 << 20, 3, True), _dense_block(70000, 4, False)]
+    noise = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    fr, data = bytearray(hdr), bytearray()
+    for i, (body, out) in enumerate(blocks):
+        fr += struct.pack("<I", len(body)) + body; data += out
+        if i == 1: fr += struct.pack("<I", len(noise) | 0x80000000) + noise; data += noise
+    fr += struct.pack("<I", 0)
+    want, used = oracle.decompress_frame(bytes(fr), len(data) + 8)
+    assert want == bytes(data) and used == len(fr)
+    frames.append(("hand-made", dict(bsid=7, indep=1), bytes(data), bytes(fr)))
+    for mode in ("0", "1", "2"):
+        os.environ["LZ4F_MI355X_DENSE_MODE"] = mode
+        L.lz4f_mi355x_release_engines()
+        try:
+            eng = Engine(0)
+            for name, kw, data_b, frb in frames:
+                out, used = gpu_decompress_frame(L, frb, len(data_b) + 8)
+                assert used == len(frb) and out == data_b, (name, kw, mode)
+                dev = torch.from_numpy(np.frombuffer(frb + bytes(32), dtype=np.uint8).copy()).cuda()
+                room = len(data_b) + 16 if name == "text" else 5 * (4 << 20) + 16            # (short blocks in the middle: the device call wants every block's full room)
+                back = torch.zeros(room, dtype=torch.uint8, device="cuda")
+                eng.decompress_frame_async(dev, len(frb), back)
+                r = eng.result()
+                assert r.size == len(data_b) and r.consumed == len(frb) and back[:len(data_b)].cpu().numpy().tobytes() == data_b, (name, kw, mode)
+                assert (int(r.flags) >> 12) & PATH["wave_per_block"], (name, kw, mode, hex(int(r.flags) >> 12))
+                if name == "text": assert int(back[len(data_b):].max()) == 0, (name, kw, mode)
+                for short in (1, 5000):                                                    # room that ends inside the last block
+                    with pytest.raises(RuntimeError):
+                        gpu_decompress_frame(L, frb, len(data_b) - short)
+            eng.close()
+            # mutations: the verdict (and, when accepted, the bytes) of the oracle
+            for name, kw, data_b, base in (frames[0], frames[3]):
+                cap = len(data_b) + 8
+                diff = []
+                for i in range(40):
+                    pos = int(rng.integers(7, len(base))); x = int(rng.integers(1, 256))
+                    bad = bytearray(base); bad[pos] ^= x; bad = bytes(bad)
+                    try:
+                        want, _ = oracle.decompress_frame(bad, cap); ov = "ok"
+                    except oracle.OracleError as e:
+                        want, ov = None, str(e)
+                    try:
+                        got, _ = gpu_decompress_frame(L, bad, cap); gv = "ok"
+                    except RuntimeError as e:
+                        got, gv = None, str(e).split(" | ")[0]
+                    if (ov == "ok") != (gv == "ok") or (ov == "ok" and got != want): diff.append((pos, x, ov, gv))
+                assert not diff, (name, mode, diff[:5])
+        finally:
+            os.environ.pop("LZ4F_MI355X_DENSE_MODE", None)
+            L.lz4f_mi355x_release_engines()
+
+
 @pytest.mark.gpu
 def test_foreign_frames_never_write_past_capacity(L):
     """Foreign frames of big independent blocks go through the stretch-parallel self-index (decode_spx.cuh), whose scan learns what the
