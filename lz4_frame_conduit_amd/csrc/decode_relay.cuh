@@ -1,24 +1,33 @@
-// decode_relay.cuh -- dense payloads in big independent blocks: a workgroup per block, its waves taking the block's 64-byte payload
+// decode_relay.cuh -- dense payloads in few big independent blocks: a workgroup per block, its waves taking the block's 64-byte payload
 // windows in turn (the inner block loop of LZ4F_decompress behind
 // /root/reference/src/Codec/Compression/LZ4/Conduit.hsc:591 for what `lz4 -c` writes of text, test/Main.hs:33-36).
 //
 // Such a block is one chain of ~13-byte sequences from its first byte to its last and comes without an index; a GiB in 4 MiB blocks is
 // 256 of them.  One wave per block (decode.cuh: wave_decode_block_win, the lanes find the tokens of a window, the matches follow a
 // byte per lane) runs ~600 instructions per window one after the other - 3600 cycles per 120 bytes of output whether the bytes come
-// from memory or (decode_ring.cuh) from LDS.  But only a little of that is a chain from window to window: where the next window
-// starts and where its output goes (read the window, hop from token to token, one prefix sum: ~500 cycles).  So:
-//   - W producer waves take windows in turn.  The wave whose turn it is reads the window, hops, sums, and passes (next position, next
-//     output position) on through LDS; then it places its literals and copies its matches while the next waves are at their windows.
-//   - the output lives in a ring of 128 KiB in LDS (block position mod 131072): nothing a producer does touches memory.  Matches whose
-//     source lies below `done_op` (everything in front of it is final) go at once; the others wait until the windows in front of
-//     theirs are complete (`done_op` reaches the window's start), then the window publishes its end as the new `done_op`.
-//   - a service wave stages the payload (a KiB at a time, 4 KiB ring in LDS, kept 2 KiB ahead of the reader) and writes the ring
-//     out to memory behind `done_op`, 16 bytes per lane.
-// Tokens the lanes cannot take (length bytes beyond the first, runs that leave the window, the block's last ~100 bytes) are done one
-// sequence at a time by the wave whose turn it is, after the windows before it are complete; copies longer than a wave go straight to
-// memory (after the service wave has caught up) and are mirrored into the ring.  Same accept/reject rules as wave_decode_block_win /
-// the oracle (oracle/orc_lz4block.c: orc_lz4_decompress_safe).
-// Every wait is a poll of LDS that also looks at `stop` and gives up after ~4 M polls (a block that hangs is reported as failed).
+// from memory or from LDS (a wave with a 64 KiB ring in LDS was tried: 14.7 -> 18.9 GiB/s for the GiB).  Very little of that is a chain from
+// window to window: where the next window starts and where its output goes, and the few matches that read what the windows just
+// before them wrote.  The workgroup is built around those two chains; everything else is spread over its waves:
+//   - speculator waves: for EVERY payload position of a 64-byte group, what a window that started there would be (its length E and its
+//     output T; lane c walks the tokens from byte c on, two at a time, by the producers' rules) - into a table in LDS.  The position chain
+//     is then one LDS read per window: pos += E, op += T.
+//   - producer waves take the windows in turn: read (E, T) at the turn's position, pass (pos + E, op + T) on, and only then do the window:
+//     hop from token to token, prefix sums, literals, and the matches whose source lies below `done_op` (everything in front of it is
+//     final), a byte per lane.  The output lives in a ring of 128 KiB in LDS (block position mod 131072): nothing a producer does touches
+//     memory.  The window's other matches are left in a slot for the finishing wave - as a byte-per-lane plan when none of them reads what
+//     another writes, as a list otherwise.
+//   - the finishing wave takes the slots in window order - the block's one chain of copies, two matches a window on text - and moves
+//     `done_op` along.  A producer looks at `done_op` when that wave is RL_D windows behind its own: sooner, and most matches are left
+//     to the chain; later, and the producer stands waiting.
+//   - the service wave stages the payload (a KiB at a time, 4 KiB ring in LDS, kept 2 KiB ahead of the reader) and writes the ring out to
+//     memory behind `done_op`, 16 bytes per lane.
+// Tokens the lanes cannot take (match lengths over 219, literal-length bytes beyond the first, sequences that do not fit into 64 bytes,
+// the block's last ~100 bytes) are done one sequence at a time by the wave whose turn it is, after the windows before it are finished;
+// copies longer than a wave go straight to memory (after the service wave has caught up) and are mirrored into the ring.  Same
+// accept/reject rules as wave_decode_block_win / the oracle (oracle/orc_lz4block.c: orc_lz4_decompress_safe).
+// Every wait is a poll of LDS that also looks at `stop` and gives up after some millions of polls (a block that hangs is reported as failed).
+// Measured (tools/text_big_blocks.py, tools/relay_prof.py; NOTES_r4.md): 1 GiB of text in 4 MiB blocks 13-14.7 -> 43 GiB/s; a workgroup
+// has a CU to itself, so from ~3 blocks per CU on the wave-per-block decoder wins again (engine.hip picks by block count).
 #pragma once
 #include "decode.cuh"
 
@@ -249,7 +258,7 @@ __device__ __forceinline__ void relay_finisher(RelayLds<W>* lds, BlockOut* __res
     }
 }
 
-// ---- a producer wave ----  (`fail` / `finish` write the block's verdict)
+// ---- a producer wave ----
 template <int W>
 __device__ __forceinline__ void relay_producer(const uint32_t w, const uint8_t* __restrict__ in, uint32_t csize, uint8_t* out, uint32_t cap,
                                                RelayLds<W>* lds, BlockOut* __restrict__ entry)
@@ -546,7 +555,7 @@ __device__ __forceinline__ void relay_producer(const uint32_t w, const uint8_t* 
 #undef RL_WAIT_HOT
 }
 
-// workgroup-per-block decode of independent blocks: W producer waves + the service wave, 139 KiB of LDS (one workgroup to a CU)
+// workgroup-per-block decode of independent blocks: W producer waves, S speculator waves, the service wave, the finishing wave; 148 KiB of LDS (one workgroup to a CU)
 template <int W, int S>
 __global__ __launch_bounds__(64 * (W + S + 2)) void k_decode_blocks_relay(const uint8_t* __restrict__ frame, uint8_t* dst, BlockOut* __restrict__ table,
                                                                       const ResultRec* __restrict__ res, uint32_t n_max, uint64_t frame_cap,
