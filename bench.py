@@ -170,7 +170,7 @@ def main():
     ap.add_argument("--headline-only", action="store_true", help="skip the side legs: what the rocprofv3 summaries under profiles/ are taken with, so that their per-kernel averages are the headline launches' only")
     ap.add_argument("--foreign", action="store_true", help="the timed decode gets the bare LZ4 frame (no trailer): walk + self-index + indexed kernels")
     ap.add_argument("--cpu-sample-mib", type=int, default=512)
-    ap.add_argument("--legs", default="all", help="comma-separated side legs to run (foreign,bck,cfg2,linked,host,cck,replay,multi); what tools/prof_leg.sh profiles one at a time")
+    ap.add_argument("--legs", default="all", help="comma-separated side legs to run (foreign,bck,cfg2,dense,linked,host,cck,replay,multi); what tools/prof_leg.sh profiles one at a time")
     args = ap.parse_args()
 
     # N > 1 and not yet under a launcher: start N ranks (one process per GPU) as a CHILD process and relay its output - nothing in
@@ -365,6 +365,26 @@ def main():
                     "roofline": {"bound": "hbm", "achieved": round(a2 / (best[0] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                  "frac": round(a2 / (best[0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "algorithmic_bytes": int(a2)}}
         if want("cfg2"): side["cfg2"] = leg(cfg2)
+
+        def dense_big():
+            # what `lz4 -c` writes of text by default (test/Main.hs:33-36): 4 MiB independent blocks, no index - 256 blocks per GiB, each one chain of ~13-byte sequences
+            m, tile_n = 1 << 30, 128 << 20
+            tile = datagen.synth_text(tile_n, 99)
+            reps = m // tile_n
+            host, fsize, framer = liblz4_frame(tile, 7, reps)
+            f2 = torch.from_numpy(host).to(dev)
+            tx = torch.from_numpy(tile).to(dev).repeat(reps)
+            b2 = torch.empty(m, dtype=torch.uint8, device=dev)
+            best = None
+            good = True
+            for _ in range(3):
+                spoil(b2)
+                eng.decompress_frame_async(f2, fsize, b2); rd = eng.result(); td = eng.get_timing()
+                good = good and bool(rd.size == m and rd.consumed == fsize and torch.equal(b2, tx))
+                if best is None or td["decompress_total"] < best: best = td["decompress_total"]
+            return {"workload": "decompress-only, 1 GiB of synthetic text pre-framed at 4 MiB independent blocks by %s, bare LZ4 frame, device-resident: a workgroup per block "
+                                "(decode_relay.cuh)" % framer, "decompress_ms": round(best, 3), "decompress_GiBs": round(m / (best * 1e-3) / GIB, 1), "roundtrip_verified": good}
+        if want("dense"): side["text_4mib_independent_blocks"] = leg(dense_big)
 
         def linked_default():
             m = 1 << 30
