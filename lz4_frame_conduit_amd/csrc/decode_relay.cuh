@@ -61,6 +61,9 @@ constexpr uint32_t RL_EXT_MAX = 200u;      // the lanes take tokens with one mat
 #ifndef RL_HOT
 #define RL_HOT 1        // the turn and done_op polls: without s_sleep
 #endif
+#ifndef RL_SLEEP
+#define RL_SLEEP 1      // s_sleep between the polls that are not on a chain (x 64 cycles)
+#endif
 #ifndef RL_D
 #define RL_D 3          // a producer looks at done_op when the finishing wave is this many windows behind its own, or fewer (<= RL_Q)
 #endif
@@ -276,7 +279,7 @@ __device__ __forceinline__ void relay_producer(const uint32_t w, const uint8_t* 
       while (!(cond)) {                                                                                    \
           if (uni(RL_V32(lds->stop))) { ok_ = false; break; }                                              \
           if (++spins_ > RL_SPIN_CAP) { verdict(-1); ok_ = false; break; }                                 \
-          __builtin_amdgcn_s_sleep(1);                                                                     \
+          __builtin_amdgcn_s_sleep(RL_SLEEP);                                                              \
       }                                                                                                    \
       RL_FENCE();                                                                                          \
       if (!ok_) return; }

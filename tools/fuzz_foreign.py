@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Development (GPU box): single-byte mutations of a FOREIGN frame of big independent blocks with long sequences (liblz4's bytes of synth50 + a ragged tail: the
-stretch finder, the self-feeding copy kernel); the verdict must be the oracle's and an accepted frame must decode to the oracle's bytes.  argv: seed mutations [bsid]"""
+stretch finder, the self-feeding copy kernel) - or, with a fourth argument "text", of text (dense: the workgroup-per-block decoder of decode_relay.cuh; LZ4F_MI355X_DENSE_MODE=2 for the
+wave-per-block one); the verdict must be the oracle's and an accepted frame must decode to the oracle's bytes.  argv: seed mutations [bsid] [text]"""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -11,6 +12,7 @@ rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 n_mut = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 bsid = int(sys.argv[3]) if len(sys.argv) > 3 else 7
 data = np.concatenate([datagen.synth50(9 << 20, int(rng.integers(1 << 30))), rng.integers(0, 256, 70001, dtype=np.uint8)]).tobytes()
+if len(sys.argv) > 4 and sys.argv[4] == "text": data = datagen.synth_text(9 << 20, int(rng.integers(1 << 30))).tobytes()
 frame = oracle.conduit_compress(data, oracle.mkprefs(bsid=bsid, indep=1))
 cap = len(data) + 8
 diff = 0; t0 = time.time()
