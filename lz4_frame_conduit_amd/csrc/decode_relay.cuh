@@ -35,6 +35,7 @@ namespace lz4f {
 
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 
+constexpr uint32_t RL_QW = 16u;            // windows the walker may be ahead of the finishing wave
 constexpr uint32_t RL_Q = 8u;              // windows posted to the finishing wave and not finished yet, at most
 
 template <int W>
@@ -42,7 +43,8 @@ struct RelayLds {
     alignas(16) uint8_t ring[131072];              // output byte at block position p: ring[p & 0x1FFFF]
     alignas(16) uint8_t stage[4096];               // payload byte q: stage[q & 4095] for st_lo <= q < st_end
     alignas(16) uint32_t et[2048];                 // et[q & 2047] = ((q >> 11) + 1) << 19 | T << 7 | E: a window that starts at payload byte q is E bytes long and makes T bytes (E = 0: not for the lanes)
-    alignas(8) unsigned long long turn[16];        // producer w's next window: pos | tag << 24, op | tag << 24 (one 64-bit write)
+    alignas(16) unsigned long long wq[RL_QW][2];   // the walker's list of windows: [0] = (op | tag << 24) << 32 | pos | tag << 24 (one 64-bit write), [1] = 1 << 31 (a sequence to be done alone) | T << 7 | E
+    alignas(8) unsigned long long mail;            // ... and where such a sequence left off, back to the walker (same packing)
     alignas(8) uint32_t st_lo; uint32_t st_end;    // (read as one 64-bit word)
     uint32_t done_op;                              // output below this is final (and in the ring)
     uint32_t flushed;                              // output below this is in memory
@@ -65,7 +67,10 @@ constexpr uint32_t RL_EXT_MAX = 200u;      // the lanes take tokens with one mat
 #define RL_SLEEP 1      // s_sleep between the polls that are not on a chain (x 64 cycles)
 #endif
 #ifndef RL_D
-#define RL_D 3          // a producer looks at done_op when the finishing wave is this many windows behind its own, or fewer (<= RL_Q)
+#define RL_D 6          // a producer's first look at done_op: when the finishing wave is this many windows behind its own, or fewer (<= RL_Q)
+#endif
+#ifndef RL_DPOST
+#define RL_DPOST 4      // ... and its last
 #endif
 #ifndef RELAY_W
 #define RELAY_W 9      // producer waves
@@ -93,14 +98,14 @@ __device__ __forceinline__ void relay_service(const uint8_t* __restrict__ in, ui
     for (;;) {
         const uint32_t stop = uni(RL_V32(lds->stop));
         bool worked = false;
-        // -- payload: keep [hint, hint + 2 KiB) staged --
+        // -- payload: keep [hint - 1 KiB, hint + 2 KiB) staged (the walker is up to 16 windows ahead of the producers' reads) --
         const uint32_t hint = uni(RL_V32(lds->pos_hint));
         if (!stop) {
             if (hint >= st_end + 1024u || hint < st_lo) {                    // the reader jumped (a long literal run)
                 st_lo = st_end = hint & ~1023u;
                 if (lane == 0) RL_V64(lds->st_lo) = ((unsigned long long)st_end << 32) | st_lo;
             }
-            if (st_end < hint + 2048u + 128u && st_end < lim) {
+            if (st_end < hint + 2048u && st_end < lim) {                      // (the chunk this one replaces ends 3 KiB in front of it: a KiB behind `hint`, where the producers may still be reading)
                 const uint64_t a = (uint64_t)st_end + 16u * lane;
                 v4u_t v = {0u, 0u, 0u, 0u};
                 if (a + 16 <= readable) v = *(const v4u_ua*)(in + a);
@@ -222,28 +227,42 @@ __device__ __forceinline__ void relay_finisher(RelayLds<W>* lds, BlockOut* __res
 {
     const uint32_t lane = lane_id();
     lds_u8* const ring = (lds_u8*)lds->ring;
+    // A window's slot is read ahead - header, plan and list in one go, while the window before it waits for its bytes out of the ring: the LDS
+    // performs a wave's reads in order, so what comes back behind a header with the right tag is what was written in front of it; a header
+    // with the old tag means reading again.
+    unsigned long long h = 0, pl = 0, tv = 0;
+    auto read_slot = [&](uint32_t kk) {
+        volatile lds_u64* const s_ = (volatile lds_u64*)lds->slot[kk % RL_Q];
+        h = s_[0];
+        pl = *(volatile lds_u64*)&lds->plan[kk % RL_Q][lane];
+        tv = s_[1u + (lane < 22u ? lane : 0u)];
+    };
+    read_slot(0);
     for (uint32_t k = 0;; k++) {
-        volatile lds_u64* const sl = (volatile lds_u64*)lds->slot[k % RL_Q];
         const uint32_t tagk = (k / RL_Q + 1u) & 0xFFFFu;
-        unsigned long long h = 0;
         uint32_t spins = 0;
         DBP(const unsigned long long f0 = clock64();)
-        while ((h = sl[0], (uni((uint32_t)h) >> 16) != tagk)) {
+        while ((uni((uint32_t)h) >> 16) != tagk) {
             if ((++spins & 31u) == 0u) {
                 if (uni(RL_V32(lds->stop))) return;
                 if (spins > 4u * RL_SPIN_CAP) { if (lane == 0) { entry->dst_size = (uint32_t)-1; RL_V32(lds->stop) = 1u; } return; }
             }
+            read_slot(k);
         }
         RL_FENCE();
         const uint32_t count = uni((uint32_t)h) & 0xFFFFu, op_end = uni((uint32_t)(h >> 32));
+        const unsigned long long pl_k = pl, tv_k = tv;
         DBP(const unsigned long long f1 = clock64();)
-        if (count == 0x8000u) {                                              // one read and one write for all of them
-            const unsigned long long pl = *(volatile lds_u64*)&lds->plan[k % RL_Q][lane];
-            if ((uint32_t)pl != 0xFFFFFFFFu) { const uint8_t b = ring[(uint32_t)(pl >> 32) & RL_MASK]; ring[(uint32_t)pl & RL_MASK] = b; }
-        } else if (count) {
-            const unsigned long long tv = sl[1u + (lane < count ? lane : 0u)];
-            const uint32_t tlo = (uint32_t)tv, thi = (uint32_t)(tv >> 32);
-            for (uint32_t j = 0; j < count; j++) {
+        {                                                                    // the planned ones: one read and one write for all of them
+            const bool mine = (count & 0x8000u) && (uint32_t)pl_k != 0xFFFFFFFFu;
+            uint8_t b = 0;
+            if (mine) b = ring[(uint32_t)(pl_k >> 32) & RL_MASK];
+            read_slot(k + 1);                                                // (on its way together with the ring's bytes)
+            if (mine) ring[(uint32_t)pl_k & RL_MASK] = b;
+        }
+        if (const uint32_t nlist = count & 0x7FFFu) {                        // the listed ones, in order
+            const uint32_t tlo = (uint32_t)tv_k, thi = (uint32_t)(tv_k >> 32);
+            for (uint32_t j = 0; j < nlist; j++) {
                 const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)tlo, (int)j), ok = (uint32_t)__builtin_amdgcn_readlane((int)thi, (int)j);
                 const uint32_t dk = lo & 0xFFFFFFu, lk = lo >> 24;
                 for (uint32_t c = 0; c < lk; c += WAVE) {                    // (up to 219 bytes: 64 at a time)
@@ -257,7 +276,63 @@ __device__ __forceinline__ void relay_finisher(RelayLds<W>* lds, BlockOut* __res
         RL_FENCE();
         if (lane == 0) { RL_V32(lds->done_op) = op_end; RL_V32(lds->fin_count) = k + 1u; }
         DBP(if (lane == 0 && blockIdx.x < 16) { const unsigned long long f2 = clock64(); atomicAdd(&g_dbprof[20], f1 - f0); atomicAdd(&g_dbprof[21], f2 - f1); atomicAdd(&g_dbprof[22], 1ull);
-             if (count == 0x8000u) atomicAdd(&g_dbprof[23], 1ull); else atomicAdd(&g_dbprof[24], (unsigned long long)count); })
+             if (count & 0x8000u) atomicAdd(&g_dbprof[23], 1ull); atomicAdd(&g_dbprof[24], (unsigned long long)(count & 0x7FFFu)); })
+    }
+}
+
+// ---- the walker: the chain of positions ----
+// pos += E(pos), op += T(pos), one read of the speculators' table per window, and the window goes on a list for the producers.  One wave does
+// nothing else: handing the position from producer to producer (a write, the next wave's poll, its read of the table) was three LDS trips per
+// window on the block's critical chain; this is one.  A window the lanes cannot take (E = 0, the block's end) goes on the list marked as a
+// single sequence; the producer that gets it reports back where it left off.
+template <int W>
+__device__ __forceinline__ void relay_walker(uint32_t csize, uint32_t cap, RelayLds<W>* lds, BlockOut* __restrict__ entry)
+{
+    const uint32_t lane = lane_id();
+    auto fail = [&]() { if (lane == 0) { entry->dst_size = (uint32_t)-1; RL_V32(lds->stop) = 1u; } };
+    uint32_t pos = 0, op = 0, fin_seen = 0;
+    for (uint32_t k = 0;; k++) {
+        uint32_t spins = 0;
+        while (k - fin_seen >= RL_QW) {                                      // (list entry k mod 16 is free once window k - 16 is finished)
+            fin_seen = uni(RL_V32(lds->fin_count));
+            if (k - fin_seen < RL_QW) break;
+            if (uni(RL_V32(lds->stop))) return;
+            if (++spins > RL_SPIN_CAP) { fail(); return; }
+            __builtin_amdgcn_s_sleep(RL_SLEEP);
+        }
+        uint32_t etv = 0;
+        if (pos <= csize && csize - pos >= 96u) {
+            // (an entry of this lap of the table: the payload under it is staged)
+            spins = 0;
+            while ((etv = uni(*(volatile lds_u32*)((lds_u32*)lds->et + (pos & 2047u))), (etv >> 19) != (pos >> 11) + 1u)) {
+                if ((++spins & 31u) == 0u) {
+                    if (uni(RL_V32(lds->stop))) return;
+                    if (spins > 4u * RL_SPIN_CAP) { fail(); return; }
+                }
+            }
+        }
+        // (E bytes of payload make T bytes; with T + 12 bytes of room none of the window's sequences can be the last one or run into the end-of-block rules)
+        const uint32_t e = etv & 127u, t = (etv >> 7) & 4095u;
+        const bool lanes = e != 0u && (uint64_t)op + t + 12u <= cap;
+        const uint32_t tagk = (k / RL_QW) % 255u + 1u;
+        if (lane == 0) {
+            RL_V64(lds->wq[k % RL_QW][1]) = lanes ? (unsigned long long)(etv & 0x7FFFFu) : 0x80000000ull;
+            RL_V64(lds->wq[k % RL_QW][0]) = ((unsigned long long)(op | (tagk << 24)) << 32) | (pos | (tagk << 24));
+        }
+        if (lanes) { pos += e; op += t; }
+        else {
+            const uint32_t mtag = k % 255u + 1u;
+            unsigned long long m = 0;
+            spins = 0;
+            while ((m = RL_V64(lds->mail), uni((uint32_t)m >> 24) != mtag || uni((uint32_t)(m >> 32) >> 24) != mtag)) {
+                if (uni(RL_V32(lds->stop))) return;
+                if (++spins > 4u * RL_SPIN_CAP) { fail(); return; }
+                __builtin_amdgcn_s_sleep(RL_SLEEP);
+            }
+            pos = uni((uint32_t)m) & 0xFFFFFFu; op = uni((uint32_t)(m >> 32)) & 0xFFFFFFu;
+            if (lane == 0) RL_V64(lds->mail) = 0ull;                           // (taken: the tag comes round again every 255 windows)
+        }
+        if (lane == 0) RL_V32(lds->pos_hint) = pos;
     }
 }
 
@@ -306,35 +381,21 @@ __device__ __forceinline__ void relay_producer(const uint32_t w, const uint8_t* 
     };
     uint32_t visit = 0;
     for (;;) {
-        // ---- my turn? ----
+        // ---- my next window, from the walker's list ----
         DBP(const unsigned long long y0 = clock64();)
         visit++;
-        const uint32_t tag = (visit - 1u) % 255u + 1u, wk = (visit - 1u) * W + w;      // (wk: the window's number)
+        const uint32_t wk = (visit - 1u) * W + w, tag = (wk / RL_QW) % 255u + 1u;       // (wk: the window's number)
         uint32_t pos = 0, op = 0;
         {
             unsigned long long t = 0;
-            RL_WAIT_HOT((t = RL_V64(lds->turn[w]), uni((uint32_t)t >> 24) == tag && uni((uint32_t)(t >> 32) >> 24) == tag));
+            RL_WAIT((t = RL_V64(lds->wq[wk % RL_QW][0]), uni((uint32_t)t >> 24) == tag && uni((uint32_t)(t >> 32) >> 24) == tag));
             pos = uni((uint32_t)t) & 0xFFFFFFu; op = uni((uint32_t)(t >> 32)) & 0xFFFFFFu;
         }
         DBP(const unsigned long long y1 = clock64();)
-        const uint32_t nw = w + 1 == W ? 0u : w + 1u, ntag = (w + 1 == W ? visit : visit - 1u) % 255u + 1u;
-        auto pass_turn = [&](uint32_t npos, uint32_t nop) {
-            RL_FENCE();
-            if (lane == 0) {
-                RL_V32(lds->pos_hint) = npos;
-                RL_V64(lds->turn[nw]) = ((unsigned long long)(nop | (ntag << 24)) << 32) | (npos | (ntag << 24));
-            }
-        };
-        // ---- the lanes' path (decode.cuh has the why of every step) ----
-        uint32_t etv = 0;
-        if (pos <= csize && csize - pos >= 96u) {
-            // what a window at `pos` is comes out of the speculators' table (an entry of this lap of the table: the payload under it is staged)
-            RL_WAIT_HOT((etv = uni(*(volatile lds_u32*)((lds_u32*)lds->et + (pos & 2047u))), (etv >> 19) == (pos >> 11) + 1u));
-        }
-        // (E bytes of payload make T bytes; with T + 12 bytes of room none of the window's sequences can be the last one or run into the end-of-block rules)
+        const uint32_t etv = uni((uint32_t)RL_V64(lds->wq[wk % RL_QW][1]));
         const uint32_t spec_e = etv & 127u, spec_t = (etv >> 7) & 4095u;
-        if (spec_e && (uint64_t)op + spec_t + 12u <= cap) {
-            pass_turn(pos + spec_e, op + spec_t);                            // ---- the next wave goes on from here ----
+        // ---- the lanes' path (decode.cuh has the why of every step) ----
+        if (!(etv >> 31)) {
             const uint32_t d = lds32(pos + lane);
             DBP(asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long y2 = clock64();)
             const uint32_t t = d & 0xFFu, litn = t >> 4, ml = t & 15u, e1 = (d >> 8) & 0xFFu;
@@ -392,13 +453,23 @@ __device__ __forceinline__ void relay_producer(const uint32_t w, const uint8_t* 
                         base = nbase;
                     }
                 };
-                // matches whose source is final already go now - looked at when the finishing wave is at most RL_D windows behind: the earlier
-                // the look, the more matches are left to that wave (it is the block's one chain of copies: two or three matches a window keep it
-                // ahead of the turn, five do not), the later, the longer this wave stands here
+                // Matches whose source is final already (below done_op) go now.  The first look comes when the finishing wave is at most RL_D windows
+                // behind this one; the looks go on - each taking what has become final since - until that wave is RL_DPOST windows behind, and only
+                // what is left then is left to it (it is the block's one chain of copies: every match it does not get shortens the block's time).
                 RL_WAIT((int32_t)(uni(RL_V32(lds->fin_count)) + RL_D - wk) > 0);
-                const uint32_t snap = uni(RL_V32(lds->done_op));
-                const bool early = is_tok && mlen <= WAVE && (int32_t)(snap - (mdst - off + mlen)) >= 0;
-                if (__ballot(early)) rounds(early);
+                bool early = false;
+                for (uint32_t looks = 0;; looks++) {
+                    const uint32_t fc = uni(RL_V32(lds->fin_count)), snap = uni(RL_V32(lds->done_op));      // (done_op is written in front of fin_count: this done_op is at least that window's)
+                    const bool ready = is_tok && !early && mlen <= WAVE && (int32_t)(snap - (mdst - off + mlen)) >= 0;
+                    const uint64_t rm = __ballot(ready);
+                    if (rm) { rounds(ready); early = early || ready; }
+                    if ((int32_t)(fc + RL_DPOST - wk) > 0 || !__ballot(is_tok && !early)) break;
+                    if (!rm) {
+                        if (uni(RL_V32(lds->stop))) return;
+                        if (looks > RL_SPIN_CAP) { verdict(-1); return; }
+                        __builtin_amdgcn_s_sleep(RL_SLEEP);
+                    }
+                }
                 DBP(const unsigned long long y4 = clock64();)
                 // the others go to the finishing wave, in stream order (slot k mod 16: free once window k - 16 is finished)
                 const bool latet = is_tok && !early;
@@ -408,15 +479,20 @@ __device__ __forceinline__ void relay_producer(const uint32_t w, const uint8_t* 
                     lds_u64* const sl = (lds_u64*)lds->slot[wk % RL_Q];
                     uint32_t count = (uint32_t)__builtin_popcountll(late);
                     if (count) {
-                        // none of them reads what another one of them writes (every source ends in front of the first one's place; the exact test,
-                        // pair by pair, found 3 % more windows and cost more than it gave), 64 bytes at most: a lane per byte
-                        const uint32_t mc = latet ? mlen : 0u;
-                        const uint32_t inc = dpp_incl_scan_add(mc), exs = inc - mc;
+                        // Those that read nothing another one of them writes (the source ends in front of the first one's place; the exact test, pair
+                        // by pair, found 3 % more and cost more than it gave) go as a byte-per-lane plan, 64 bytes at most: one read and one write for
+                        // the finishing wave, whatever their number.  The others - they are later in the stream than what they read, and the planned
+                        // ones read nothing of theirs - follow as a list, in order.
                         const bool clash = latet && mdst - off + mlen > (uint32_t)__builtin_amdgcn_readlane((int)mdst, (int)__builtin_ctzll(late));
-                        const bool flat = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63) <= WAVE && !__ballot(clash);
-                        if (flat) {
+                        bool planned = latet && !clash;
+                        const uint32_t mc = planned ? mlen : 0u;
+                        const uint32_t inc = dpp_incl_scan_add(mc), exs = inc - mc;
+                        if ((uint32_t)__builtin_amdgcn_readlane((int)inc, 63) > WAVE) planned = false;      // (too many bytes for one step: all of them by the list)
+                        const uint64_t pm = __ballot(planned), lm = late & ~pm;
+                        count = (uint32_t)__builtin_popcountll(lm);
+                        if (pm) {
                             xp[lane] = 0u;
-                            if (latet) xp[exs] = lane + 1u;
+                            if (planned) xp[exs] = lane + 1u;
                             const uint32_t k1 = dpp_incl_scan_max(xp[lane]);
                             const uint32_t kk = ((k1 ? k1 : 1u) - 1u) << 2;
                             const uint32_t pa = (uint32_t)__builtin_amdgcn_ds_bpermute((int)kk, (int)pa_mine),
@@ -424,10 +500,11 @@ __device__ __forceinline__ void relay_producer(const uint32_t w, const uint8_t* 
                             const uint32_t bi = lane - (pb >> 16), bd = pa & 0xFFFFFFu;
                             const bool mine = k1 && bi < (pa >> 24);
                             ((lds_u64*)lds->plan[wk % RL_Q])[lane] = mine ? ((unsigned long long)(bd - (pb & 0xFFFFu) + bi) << 32) | (bd + bi) : 0xFFFFFFFFull;
-                            count = 0x8000u;
-                        } else {
-                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(late >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)late, 0u));
-                            if (latet) sl[1u + rank] = ((unsigned long long)off << 32) | pa_mine;
+                            count |= 0x8000u;
+                        }
+                        if (lm) {
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+                            if (latet && !planned) sl[1u + rank] = ((unsigned long long)off << 32) | pa_mine;
                         }
                     }
                     RL_FENCE();
@@ -551,7 +628,8 @@ __device__ __forceinline__ void relay_producer(const uint32_t w, const uint8_t* 
             mirror_and_publish(op, mlen);
         }
         op += mlen;
-        pass_turn(npos, op);
+        RL_FENCE();
+        if (lane == 0) RL_V64(lds->mail) = ((unsigned long long)(op | ((wk % 255u + 1u) << 24)) << 32) | (npos | ((wk % 255u + 1u) << 24));      // (the walker goes on from here)
         if (lane == 0) RL_V64(lds->slot[wk % RL_Q][0]) = ((unsigned long long)op << 32) | ((((wk / RL_Q) + 1u) & 0xFFFFu) << 16);     // (nothing left to finish: the finishing wave moves on)
     }
 #undef RL_WAIT
@@ -560,11 +638,11 @@ __device__ __forceinline__ void relay_producer(const uint32_t w, const uint8_t* 
 
 // workgroup-per-block decode of independent blocks: W producer waves, S speculator waves, the service wave, the finishing wave; 148 KiB of LDS (one workgroup to a CU)
 template <int W, int S>
-__global__ __launch_bounds__(64 * (W + S + 2)) void k_decode_blocks_relay(const uint8_t* __restrict__ frame, uint8_t* dst, BlockOut* __restrict__ table,
+__global__ __launch_bounds__(64 * (W + S + 3)) void k_decode_blocks_relay(const uint8_t* __restrict__ frame, uint8_t* dst, BlockOut* __restrict__ table,
                                                                       const ResultRec* __restrict__ res, uint32_t n_max, uint64_t frame_cap,
                                                                       const uint32_t* __restrict__ only_if)
 {
-    static_assert(W >= 2 && W <= 16 && S >= 1 && W + S + 2 <= 16, "turn slots, 1024 threads");
+    static_assert(W >= 2 && S >= 1 && W + S + 3 <= 16, "1024 threads");
     __shared__ RelayLds<W> lds;
     if (res->status != ST_OK) return;
     if (only_if && *only_if == 0) return;
@@ -585,12 +663,13 @@ __global__ __launch_bounds__(64 * (W + S + 2)) void k_decode_blocks_relay(const 
         if (threadIdx.x == 0) table[b].dst_size = (uint32_t)-1;
         return;
     }
-    if (threadIdx.x < 16) lds.turn[threadIdx.x] = threadIdx.x == 0 ? ((1ull << 24) << 32) | (1ull << 24) : 0ull;    // producer 0, visit 1: position 0, output 0
-    for (uint32_t i = threadIdx.x; i < 2048u; i += 64 * (W + S + 2)) lds.et[i] = 0u;
+    if (threadIdx.x < RL_QW) lds.wq[threadIdx.x][0] = 0ull;
+    for (uint32_t i = threadIdx.x; i < 2048u; i += 64 * (W + S + 3)) lds.et[i] = 0u;
     if (threadIdx.x < RL_Q) lds.slot[threadIdx.x][0] = 0ull;                                  // (lap 0: no entry)
-    if (threadIdx.x == 0) { lds.st_lo = 0; lds.st_end = 0; lds.done_op = 0; lds.flushed = 0; lds.pos_hint = 0; lds.stop = 0; lds.flush_req = 0; lds.fin_count = 0; }
+    if (threadIdx.x == 0) { lds.st_lo = 0; lds.st_end = 0; lds.done_op = 0; lds.flushed = 0; lds.pos_hint = 0; lds.stop = 0; lds.flush_req = 0; lds.fin_count = 0; lds.mail = 0ull; }
     __syncthreads();
-    if (w == W + S + 1) relay_finisher<W>(&lds, &table[b]);
+    if (w == W + S + 2) relay_walker<W>(csz, e.dst_size, &lds, &table[b]);
+    else if (w == W + S + 1) relay_finisher<W>(&lds, &table[b]);
     else if (w == W + S) relay_service<W>(frame + e.src_off, csz, frame_cap - e.src_off, dst + e.dst_off, &lds);
     else if (w >= W) relay_speculator<W, S>(w - W, &lds);
     else relay_producer<W>(w, frame + e.src_off, csz, dst + e.dst_off, e.dst_size, &lds, &table[b]);
