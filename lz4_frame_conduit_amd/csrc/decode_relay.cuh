@@ -64,7 +64,7 @@ constexpr uint32_t RL_EXT_MAX = 200u;      // the lanes take tokens with one mat
 #define RL_HOT 1        // the turn and done_op polls: without s_sleep
 #endif
 #ifndef RL_SLEEP
-#define RL_SLEEP 1      // s_sleep between the polls that are not on a chain (x 64 cycles)
+#define RL_SLEEP 8      // s_sleep between the polls that are not on a chain (x 64 cycles)
 #endif
 #ifndef RL_D
 #define RL_D 6          // a producer's first look at done_op: when the finishing wave is this many windows behind its own, or fewer (<= RL_Q)
@@ -276,7 +276,7 @@ __device__ __forceinline__ void relay_finisher(RelayLds<W>* lds, BlockOut* __res
         RL_FENCE();
         if (lane == 0) { RL_V32(lds->done_op) = op_end; RL_V32(lds->fin_count) = k + 1u; }
         DBP(if (lane == 0 && blockIdx.x < 16) { const unsigned long long f2 = clock64(); atomicAdd(&g_dbprof[20], f1 - f0); atomicAdd(&g_dbprof[21], f2 - f1); atomicAdd(&g_dbprof[22], 1ull);
-             if (count & 0x8000u) atomicAdd(&g_dbprof[23], 1ull); atomicAdd(&g_dbprof[24], (unsigned long long)(count & 0x7FFFu)); })
+             if (count & 0x8000u) atomicAdd(&g_dbprof[23], 1ull); atomicAdd(&g_dbprof[24], (unsigned long long)(count & 0x7FFFu)); if (spins == 0) atomicAdd(&g_dbprof[25], 1ull); })
     }
 }
 
@@ -513,7 +513,7 @@ __device__ __forceinline__ void relay_producer(const uint32_t w, const uint8_t* 
                 DBP(const unsigned long long c_e = __builtin_popcountll(__ballot(early)), c_o = __builtin_popcountll(late);)
                 DBP(if (lane == 0 && blockIdx.x < 16) { const unsigned long long y6 = clock64(); atomicAdd(&g_dbprof[0], y1 - y0); atomicAdd(&g_dbprof[1], y2 - y1); atomicAdd(&g_dbprof[2], y3 - y2);
                      atomicAdd(&g_dbprof[3], y4 - y3); atomicAdd(&g_dbprof[4], y5 - y4); atomicAdd(&g_dbprof[5], y6 - y5); atomicAdd(&g_dbprof[6], 1ull);
-                     atomicAdd(&g_dbprof[7], c_e); atomicAdd(&g_dbprof[9], c_o); })
+                     atomicAdd(&g_dbprof[7], c_e); atomicAdd(&g_dbprof[9], c_o); atomicAdd(&g_dbprof[26], (unsigned long long)(wk - RL_V32(lds->fin_count))); })
                 continue;
             }
         }

@@ -26,3 +26,4 @@ print("producer, cycles per window: wait for the turn %d, table entry + pass + w
 ng = max(z[18], 1); nf = max(z[22], 1)
 print("speculators: groups %d (%.2f per window), cycles per group: waiting %d, working %d (%.1f two-token steps)" % (z[18], z[18] / nw, z[16] // ng, z[17] // ng, z[19] / ng))
 print("finishing wave: windows %d, cycles per window: waiting for the slot %d, copying + publishing %d; byte-per-lane plans %.2f of the windows, listed matches %.2f per window" % (z[22], z[20] // nf, z[21] // nf, z[23] / nf, z[24] / nf))
+print("finishing wave found the slot it had read ahead posted: %.2f of the windows; a producer posts %.2f windows ahead of the finishing wave" % (z[25] / nf, z[26] / nw))
