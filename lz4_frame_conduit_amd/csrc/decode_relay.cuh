@@ -9,24 +9,23 @@
 // window to window: where the next window starts and where its output goes, and the few matches that read what the windows just
 // before them wrote.  The workgroup is built around those two chains; everything else is spread over its waves:
 //   - speculator waves: for EVERY payload position of a 64-byte group, what a window that started there would be (its length E and its
-//     output T; lane c walks the tokens from byte c on, two at a time, by the producers' rules) - into a table in LDS.  The position chain
-//     is then one LDS read per window: pos += E, op += T.
-//   - producer waves take the windows in turn: read (E, T) at the turn's position, pass (pos + E, op + T) on, and only then do the window:
-//     hop from token to token, prefix sums, literals, and the matches whose source lies below `done_op` (everything in front of it is
-//     final), a byte per lane.  The output lives in a ring of 128 KiB in LDS (block position mod 131072): nothing a producer does touches
-//     memory.  The window's other matches are left in a slot for the finishing wave - as a byte-per-lane plan when none of them reads what
-//     another writes, as a list otherwise.
-//   - the finishing wave takes the slots in window order - the block's one chain of copies, two matches a window on text - and moves
-//     `done_op` along.  A producer looks at `done_op` when that wave is RL_D windows behind its own: sooner, and most matches are left
-//     to the chain; later, and the producer stands waiting.
-//   - the service wave stages the payload (a KiB at a time, 4 KiB ring in LDS, kept 2 KiB ahead of the reader) and writes the ring out to
-//     memory behind `done_op`, 16 bytes per lane.
+//     output T; lane c walks the tokens from byte c on, two at a time, by the producers' rules) - into a table in LDS.
+//   - the walker wave: the chain of positions is then one LDS read per window: pos += E, op += T; the windows go on a list in LDS.
+//   - producer waves take the windows off the list in rotation and do them: hop from token to token, prefix sums, literals, and the
+//     matches whose source lies below `done_op` (everything in front of it is final), a byte per lane - looking at `done_op` again and
+//     again while the finishing wave is still a few windows away.  The output lives in a ring of 128 KiB in LDS (block position mod
+//     131072): nothing a producer does touches memory.  What is left of the window's matches goes into a slot for the finishing wave:
+//     those that read nothing another of them writes as a byte-per-lane plan, the others as a list behind it.
+//   - the finishing wave takes the slots in window order - the block's one chain of copies - and moves `done_op` along: a plan is one
+//     read and one write whatever its number of matches (75 % of the windows have only that), a listed match ~600 cycles.
+//   - the service wave stages the payload (a KiB at a time, 4 KiB ring in LDS, kept 2 KiB ahead of the walker and 1 KiB behind it) and
+//     writes the ring out to memory behind `done_op`, 16 bytes per lane.
 // Tokens the lanes cannot take (match lengths over 219, literal-length bytes beyond the first, sequences that do not fit into 64 bytes,
-// the block's last ~100 bytes) are done one sequence at a time by the wave whose turn it is, after the windows before it are finished;
+// the block's last ~100 bytes) are done one sequence at a time by the producer that gets them (the walker waits for its answer), after the windows before are finished;
 // copies longer than a wave go straight to memory (after the service wave has caught up) and are mirrored into the ring.  Same
 // accept/reject rules as wave_decode_block_win / the oracle (oracle/orc_lz4block.c: orc_lz4_decompress_safe).
 // Every wait is a poll of LDS that also looks at `stop` and gives up after some millions of polls (a block that hangs is reported as failed).
-// Measured (tools/text_big_blocks.py, tools/relay_prof.py; NOTES_r4.md): 1 GiB of text in 4 MiB blocks 13-14.7 -> 43 GiB/s; a workgroup
+// Measured (tools/text_big_blocks.py, tools/relay_prof.py; NOTES_r4.md): 1 GiB of text in 4 MiB blocks 13-14.7 -> 52-53 GiB/s; a workgroup
 // has a CU to itself, so from ~3 blocks per CU on the wave-per-block decoder wins again (engine.hip picks by block count).
 #pragma once
 #include "decode.cuh"
@@ -636,7 +635,7 @@ __device__ __forceinline__ void relay_producer(const uint32_t w, const uint8_t* 
 #undef RL_WAIT_HOT
 }
 
-// workgroup-per-block decode of independent blocks: W producer waves, S speculator waves, the service wave, the finishing wave; 148 KiB of LDS (one workgroup to a CU)
+// workgroup-per-block decode of independent blocks: W producer waves, S speculator waves, the service wave, the finishing wave, the walker; 148 KiB of LDS (one workgroup to a CU)
 template <int W, int S>
 __global__ __launch_bounds__(64 * (W + S + 3)) void k_decode_blocks_relay(const uint8_t* __restrict__ frame, uint8_t* dst, BlockOut* __restrict__ table,
                                                                       const ResultRec* __restrict__ res, uint32_t n_max, uint64_t frame_cap,
