@@ -334,6 +334,7 @@ LZ4F_MI355X_API size_t lz4f_mi355x_dev_index_size(size_t srcSize, const LZ4F_pre
 #define LZ4F_MI355X_PATH_WINDOW        0x080u   /* linked frame: the single-workgroup window kernel was launched (it returns at once behind a successful indexed decode) */
 #define LZ4F_MI355X_PATH_FUSED         0x100u   /* fused parse+copy workgroups were launched (alone, or as what the others fall back to) */
 #define LZ4F_MI355X_PATH_WAVE_PER_BLOCK 0x200u  /* small independent blocks: a wave per block */
+#define LZ4F_MI355X_PATH_WORKGROUP_PER_BLOCK 0x800u /* few big independent blocks that may be dense: a workgroup per block with the window in LDS was launched beside the fused ones (the payload's density decides on the device which of the two decodes) */
 #define LZ4F_MI355X_PATH_INDEX_DROPPED 0x400u   /* set on the device: the indexed kernels refused the index, the generic ones decoded */
 /* compress calls, result.flags bit 9: the encoder's record workspace (sized for a sequence per 5.3 input bytes on average - dense text has
  * one per 6..8 - instead of the format's worst case of one per 4: lz4f_mi355x_dev_workspace_size) was used up, and the 64 KiB tiles that

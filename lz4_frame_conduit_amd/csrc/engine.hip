@@ -804,10 +804,11 @@ size_t lz4f_mi355x_engine::launch_decompress(const DecompressJob& j, lz4f_mi355x
                 // Few big blocks: a wave per block leaves the machine idle and waits out every trip to memory (13-15 GiB/s for a GiB in 4 MiB blocks);
                 // a workgroup per block with the block's window in LDS and its waves taking the payload in turns (decode_relay.cuh) is three times
                 // as fast per block - but it has a CU to itself, so from ~3 blocks per CU on the waves win again (8 GiB in 4 MiB blocks: 90 GiB/s).
-                if (j.block_size > 65536u && sw.dense_mode != 2 && (sw.dense_mode == 1 || n_max <= 3u * device_cus(device)))
+                if (j.block_size > 65536u && sw.dense_mode != 2 && (sw.dense_mode == 1 || n_max <= 3u * device_cus(device))) {
+                    plan |= LZ4F_MI355X_PATH_WORKGROUP_PER_BLOCK;
                     hipLaunchKernelGGL((k_decode_blocks_relay<RELAY_W, RELAY_S>), dim3(n_max), dim3(64 * (RELAY_W + RELAY_S + 3)), 0, st, j.d_frame, j.d_dst, tbl, (const ResultRec*)d_res, n_max, (uint64_t)j.frame_cap,
                                        (const uint32_t*)density.p);
-                else
+                } else
                 hipLaunchKernelGGL((k_decode_blocks<W>), dim3((n_max + W - 1) / W), dim3(64 * W), 0, st, j.d_frame, j.d_dst, j.dst_cap, tbl, (const ResultRec*)d_res,
                                    n_max, 0u, j.block_size, j.hist0, (uint64_t)j.frame_cap, (const uint32_t*)density.p);
                 only_if = (const uint32_t*)density.p + 1;

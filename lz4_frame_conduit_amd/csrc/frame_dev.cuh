@@ -821,9 +821,12 @@ __global__ __launch_bounds__(64) void k_density_probe(const uint8_t* __restrict_
         const uint32_t csz = e.word & 0x7FFFFFFFu;
         if (!(e.word >> 31) && csz >= 64 && e.src_off + csz <= frame_cap && (lane == 0 || b != (uint32_t)(((uint64_t)(lane - 1) * n) >> 6))) {
             const uint8_t* in = frame + e.src_off;
-            const uint32_t lim = csz < 512u ? csz - 16u : 496u;
+            // (few blocks: each lane's look is longer - 32 KiB over the frame either way, 8 KiB per block at most.  A block's first bytes have nothing to refer
+            // to: the first 512 bytes of three blocks of text are mostly literals, 25-30 payload bytes per sequence, and the frame went to the scalar parser)
+            const uint32_t want = n >= 64u ? 512u : n >= 4u ? 512u * (64u / n) : 8192u;
+            const uint32_t lim = csz < want ? csz - 16u : want - 16u;
             uint32_t pos = 0, first_end = 0;
-            while (pos < lim && seqs < 256u) {                           // (lengths only; a malformed payload just gives a number)
+            while (pos < lim && seqs < 2048u) {                          // (lengths only; a malformed payload just gives a number)
                 const uint32_t t = in[pos++];
                 uint32_t lit = t >> 4;
                 if (lit == 15) { uint32_t x; do { x = pos < lim ? in[pos] : 0u; pos++; lit += x; } while (x == 255u && pos < lim); }
@@ -832,7 +835,7 @@ __global__ __launch_bounds__(64) void k_density_probe(const uint8_t* __restrict_
                 seqs++;
                 if (seqs == 1) first_end = pos;
             }
-            if (seqs > 1) { seqs -= 1; bytes = (pos < 1024u ? pos : 1024u) - (first_end < pos ? first_end : pos); } else { seqs = 0; bytes = 0; }
+            if (seqs > 1) { seqs -= 1; bytes = (pos < want + 512u ? pos : want + 512u) - (first_end < pos ? first_end : pos); } else { seqs = 0; bytes = 0; }
         }
     }
     uint32_t st = seqs, bt = bytes;

@@ -55,7 +55,7 @@ PREF_SETS = {"default": {}, "cli": dict(bsid=7, indep=1, cck=1), "cli_bck": dict
              "indep64k_bck": dict(bsid=4, indep=1, bck=1), "linked256k_cck": dict(bsid=5, indep=0, cck=1)}
 # result.flags >> 12 (include/lz4f_mi355x.h: LZ4F_MI355X_PATH_*)
 PATH = dict(table=0x001, trailer=0x002, parallel_walk=0x004, indexed=0x008, self_index=0x010, doubling=0x020, hops=0x040, window=0x080, fused=0x100,
-            wave_per_block=0x200, dropped=0x400)
+            wave_per_block=0x200, dropped=0x400, workgroup_per_block=0x800)
 SMALL_INPUTS = ["hello20", "empty", "rep42", "ints", "hello100k", "tiny12", "tiny13"]
 
 
@@ -1331,6 +1331,7 @@ def test_dense_payloads_in_big_independent_blocks(L):
                 r = eng.result()
                 assert r.size == len(data_b) and r.consumed == len(frb) and back[:len(data_b)].cpu().numpy().tobytes() == data_b, (name, kw, mode)
                 assert (int(r.flags) >> 12) & PATH["wave_per_block"], (name, kw, mode, hex(int(r.flags) >> 12))
+                assert bool((int(r.flags) >> 12) & PATH["workgroup_per_block"]) == (mode != "2"), (name, kw, mode, hex(int(r.flags) >> 12))
                 if name == "text": assert int(back[len(data_b):].max()) == 0, (name, kw, mode)
                 for short in (1, 5000):                                                    # room that ends inside the last block
                     with pytest.raises(RuntimeError):

@@ -25,7 +25,9 @@ for i in range(n_mut):
     except oracle.OracleError as e:
         want, ov = None, str(e)
     dst = ctypes.create_string_buffer(cap); used = ctypes.c_size_t(0)
+    t1 = time.time()
     r = L.lz4f_mi355x_decompressFrame(dst, cap, bad, len(bad), ctypes.byref(used))
+    if time.time() - t1 > 0.3: print("slow: %.2f s" % (time.time() - t1), "pos", pos, "xor", x, "oracle", ov, "gpu", "ok" if not L.LZ4F_isError(r) else L.LZ4F_getErrorName(r).decode(), flush=True)
     gv = "ok" if not L.LZ4F_isError(r) else L.LZ4F_getErrorName(r).decode()
     if (ov == "ok") != (gv == "ok") or (ov == "ok" and dst.raw[:r] != want):
         diff += 1; print("pos", pos, "xor", x, "oracle", ov, "gpu", gv)
