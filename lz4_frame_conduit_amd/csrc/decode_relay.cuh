@@ -52,16 +52,13 @@ struct RelayLds {
     uint32_t flush_req;                            // a producer waits for flushed == done_op
     uint32_t pad;
     uint32_t fin_count;                            // windows the finishing wave is done with
-    alignas(8) unsigned long long slot[RL_Q][24];  // window k's matches that could not go at once, for the finishing wave: [0] = op_end << 32 | tag << 16 | count, [1 + j] = off << 32 | mlen << 24 | dst
-    alignas(8) unsigned long long plan[RL_Q][64];  // ... or (count = 0x8000) byte by byte, a lane each: src << 32 | dst (dst = 0xFFFFFFFF: nothing) - they do not depend on one another
+    alignas(8) unsigned long long slot[RL_Q][24];  // window k's matches that could not go at once, for the finishing wave: [0] = op_end << 32 | tag << 16 | count (listed ones; bit 15: there is a plan), [1 + j] = off << 32 | mlen << 24 | dst
+    alignas(8) unsigned long long plan[RL_Q][64];  // ... and (count & 0x8000) those of them that read nothing another one writes, byte by byte, a lane each: src << 32 | dst (dst = 0xFFFFFFFF: nothing)
     uint32_t expand[W][64];
 };
 constexpr uint32_t RL_MASK = 131071u;
 constexpr uint32_t RL_SPIN_CAP = 1u << 22;
 constexpr uint32_t RL_EXT_MAX = 200u;      // the lanes take tokens with one match-length byte up to this (matches of up to 219 bytes)
-#ifndef RL_HOT
-#define RL_HOT 1        // the turn and done_op polls: without s_sleep
-#endif
 #ifndef RL_SLEEP
 #define RL_SLEEP 8      // s_sleep between the polls that are not on a chain (x 64 cycles)
 #endif
@@ -357,18 +354,6 @@ __device__ __forceinline__ void relay_producer(const uint32_t w, const uint8_t* 
       }                                                                                                    \
       RL_FENCE();                                                                                          \
       if (!ok_) return; }
-    // (the two waits a window's time hangs on - the turn and done_op - poll without sleeping and look at `stop` now and then)
-#define RL_WAIT_HOT(cond)                                                                                  \
-    { uint32_t spins_ = 0; bool ok_ = true;                                                                \
-      while (!(cond)) {                                                                                    \
-          if (!RL_HOT) __builtin_amdgcn_s_sleep(1);                                                        \
-          if ((++spins_ & 31u) == 0u) {                                                                    \
-              if (uni(RL_V32(lds->stop))) { ok_ = false; break; }                                          \
-              if (spins_ > 4u * RL_SPIN_CAP) { verdict(-1); ok_ = false; break; }                          \
-          }                                                                                                \
-      }                                                                                                    \
-      RL_FENCE();                                                                                          \
-      if (!ok_) return; }
     auto staged = [&](uint32_t from, uint32_t upto) -> bool {                // payload [from, upto) is in `stage`
         const unsigned long long s = RL_V64(lds->st_lo);
         return uni((uint32_t)s) <= from && upto <= uni((uint32_t)(s >> 32));
@@ -632,7 +617,6 @@ __device__ __forceinline__ void relay_producer(const uint32_t w, const uint8_t* 
         if (lane == 0) RL_V64(lds->slot[wk % RL_Q][0]) = ((unsigned long long)op << 32) | ((((wk / RL_Q) + 1u) & 0xFFFFu) << 16);     // (nothing left to finish: the finishing wave moves on)
     }
 #undef RL_WAIT
-#undef RL_WAIT_HOT
 }
 
 // workgroup-per-block decode of independent blocks: W producer waves, S speculator waves, the service wave, the finishing wave, the walker; 148 KiB of LDS (one workgroup to a CU)
