@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development (GPU box): where this encoder's frames are bigger than liblz4's (the oracle's) on one input: sequences, literal bytes, match bytes, bytes of
 sequence overhead, and how the literal bytes fall within the 1 KiB helpings pass E1 hands out (position of the literal in its helping).
-    tools/ratio_anatomy.py [structured|text|synth50|rows256] [MiB]"""
+    tools/ratio_anatomy.py [structured|text|synth50|rows256|real] [MiB]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,6 +15,17 @@ elif what == "text": data = datagen.synth_text(n, 4)
 elif what == "rows256":
     rng = np.random.default_rng(3); a = rng.integers(0, 256, n, dtype=np.uint8).reshape(-1, 256); odd = np.arange(1, a.shape[0], 2)
     back = rng.integers(1, 100, odd.size) * 2 + 1; srcr = np.maximum(odd - back, 0); srcr -= srcr % 2; a[odd] = a[srcr]; data = a.reshape(-1)
+elif what == "real":                                                     # the image's own Python sources and headers, as tools/real_text.py takes them
+    buf = bytearray()
+    for root in ("/usr/lib/python3/dist-packages", "/usr/lib/python3.10", "/usr/local/lib/python3.10/dist-packages", "/opt/rocm/include"):
+        for dp, dn, fn in os.walk(root):
+            for f in sorted(fn):
+                if f.endswith((".py", ".h", ".hpp", ".txt", ".md", ".rst", ".json")):
+                    try: buf += open(os.path.join(dp, f), "rb").read()
+                    except OSError: pass
+            if len(buf) >= n: break
+        if len(buf) >= n: break
+    data = np.frombuffer(bytes(buf[:n]), dtype=np.uint8).copy()
 else: data = datagen.synth50(n, 3)
 def seqs(frame):
     b = bytes(frame); pos = 7; out = []; base = 0
