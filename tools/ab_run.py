@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development (GPU box): pass E1 / whole-compress time and ratio of library variants (tools/ab_build.sh), each in a child process.
     python3 tools/ab_run.py [name ...]        (no names: every lib_*.so under lz4_frame_conduit_amd/build/ab, plus the in-tree library as 'base')
-Per variant: synth50 4 GiB in 4 MiB blocks (the headline input), synth50 1 GiB in 64 KiB linked blocks, text 1 GiB in 64 KiB and in 4 MiB blocks;
+Per variant: synth50 4 GiB in 4 MiB blocks (the headline input), synth50 1 GiB in 64 KiB linked blocks, text 1 GiB in 64 KiB and in 4 MiB blocks (AB_CASES adds real_4m, real_64k: 128 MiB of real text);
 best of 3 find_matches / emit ms, ratio, and a device round trip through the in-tree decoder of that variant."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,6 +37,20 @@ if "text_64k" in cases or "text_4m" in cases:
     tx = torch.from_numpy(datagen.synth_text(64 << 20, 99)).cuda().repeat(16)
     if "text_64k" in cases: run("text_64k", tx, 4, 1)
     if "text_4m" in cases: run("text_4m", tx, 7, 1)
+if "real_4m" in cases or "real_64k" in cases:                          # real text: the image's Python sources and headers (tools/real_text.py), 128 MiB
+    import numpy as np
+    buf = bytearray()
+    for root in ("/usr/lib/python3/dist-packages", "/usr/lib/python3.10", "/usr/local/lib/python3.10/dist-packages", "/opt/rocm/include"):
+        for dp, dn, fn in os.walk(root):
+            for f in sorted(fn):
+                if f.endswith((".py", ".h", ".hpp", ".txt", ".md", ".rst", ".json")):
+                    try: buf += open(os.path.join(dp, f), "rb").read()
+                    except OSError: pass
+            if len(buf) >= (128 << 20): break
+        if len(buf) >= (128 << 20): break
+    rt = torch.from_numpy(np.frombuffer(bytes(buf[:128 << 20]), dtype=np.uint8).copy()).cuda()
+    if "real_4m" in cases: run("real_4m", rt, 7, 1)
+    if "real_64k" in cases: run("real_64k", rt, 4, 1)
 print("AB_RESULT " + json.dumps(out))
 ''' % ROOT
 names = sys.argv[1:]
