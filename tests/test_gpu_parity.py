@@ -1359,6 +1359,41 @@ def test_dense_payloads_in_big_independent_blocks(L):
             L.lz4f_mi355x_release_engines()
 
 
+def _real_text(n: int) -> bytes:
+    """Real text instead of the synthetic kind: the image's own Python sources and headers, concatenated (the GPU box runs the same image)."""
+    import os
+    buf = bytearray()
+    for root in ("/usr/lib/python3/dist-packages", "/usr/lib/python3.10", "/usr/local/lib/python3.10/dist-packages", "/opt/rocm/include"):
+        for dp, dn, fn in os.walk(root):
+            for f in sorted(fn):
+                if f.endswith((".py", ".h", ".hpp", ".txt", ".md", ".rst", ".json")):
+                    try: buf += open(os.path.join(dp, f), "rb").read()
+                    except OSError: pass
+            if len(buf) >= n: break
+        if len(buf) >= n: break
+    return bytes(buf[:n])
+
+
+@pytest.mark.gpu
+def test_real_text_both_directions_and_ratio(L):
+    """Real text (source code: longer matches and nearer repeats than the synthetic Zipf text, three times its ratio): what this library writes of it the oracle
+    decodes, what liblz4 writes of it this library decodes - 4 MiB and 64 KiB independent blocks, 64 KiB linked - and the size stays within REAL_TEXT_RATIO_TOL of
+    liblz4's.  That tolerance is what round 4 measured (11.5 % bigger; tools/real_text.py, NOTES_r4.md), not what is wanted: the test is there so that the number is
+    looked at and does not get worse unseen."""
+    REAL_TEXT_RATIO_TOL = 1.14
+    data = _real_text(24 << 20)
+    if len(data) < (8 << 20): pytest.skip("no text to speak of in this image")
+    for kw in (dict(bsid=7, indep=1), dict(bsid=4, indep=1), dict(bsid=4, indep=0)):
+        mine = gpu_compress_frame(L, data, prefs_of(kw))
+        out, used = oracle.decompress_frame(mine, cap=len(data) + 64)
+        assert out == data and used == len(mine), kw
+        ref = oracle.conduit_compress(data, oracle.mkprefs(**kw))
+        assert len(mine) <= len(ref) * REAL_TEXT_RATIO_TOL, (kw, len(mine), len(ref), len(mine) / len(ref))
+        for fr in (ref, mine):
+            back, used = gpu_decompress_frame(L, fr, len(data) + 8)
+            assert back == data and used == len(fr), kw
+
+
 @pytest.mark.gpu
 def test_foreign_frames_never_write_past_capacity(L):
     """Foreign frames of big independent blocks go through the stretch-parallel self-index (decode_spx.cuh), whose scan learns what the
